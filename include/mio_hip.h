@@ -1,0 +1,163 @@
+/*
+ * mio_hip.h -- C ABI of libmio_hip.so, the MI355X (gfx950 / CDNA4) implementation of the
+ * transformer-inference hot path of aslitaser/ml-inference-optimizer.
+ *
+ * Every entry point replaces one Python->Triton launch boundary of the reference (cited per
+ * function as reference file:line).  Conventions:
+ *   - plain C: pointers, sizes, strides; no C++ or torch types.
+ *   - every function returns 0 on success, <0 on error; mio_last_error() gives the message
+ *     (thread-local).  Nothing is allocated, no ownership changes hands: outputs and workspaces
+ *     are caller-owned device buffers.
+ *   - asynchronous on the given HIP stream (`stream` is a hipStream_t passed as void*); safe to
+ *     call concurrently from several threads/streams; graph-capturable (no sync, no malloc).
+ *   - strides are in ELEMENTS of the tensor's dtype.  The innermost (head_dim / feature)
+ *     dimension must be contiguous (stride 1) and every row start must be 16-byte aligned.
+ */
+#ifndef MIO_HIP_H
+#define MIO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIO_VERSION 100 /* 0.1.0 */
+
+typedef enum { MIO_BF16 = 0, MIO_FP16 = 1 } mio_dtype_t;
+
+typedef enum {
+  MIO_ACT_NONE = 0,
+  MIO_ACT_GELU_TANH = 1, /* kernels/triton/mlp_kernels.py:144-161, kernels/mlp/fused_mlp.py:227-231 */
+  MIO_ACT_GELU_ERF = 2,  /* kernels/triton/mlp_kernels.py:782-783, kernels/mlp/fused_mlp.py:162-163 */
+  MIO_ACT_RELU = 3,      /* kernels/triton/mlp_kernels.py:233-414 */
+  MIO_ACT_SILU = 4,      /* kernels/mlp/fused_mlp.py:166-167 */
+  MIO_ACT_SWIGLU = 5     /* kernels/triton/mlp_kernels.py:417-641 */
+} mio_act_t;
+
+typedef enum {
+  MIO_MASK_NONE = 0,
+  MIO_MASK_KEEP_U8 = 1, /* 1 = attend, 0 -> score := -1e9  (flash_attention_kernels.py:257-273) */
+  MIO_MASK_ADD_F32 = 2  /* score += mask                   (attention_kernels.py:1565-1566)      */
+} mio_mask_kind_t;
+
+int mio_version(void);
+const char* mio_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * FlashAttention-3 style tiled attention forward (prefill), online softmax, fp32 accumulators.
+ * Replaces: triton_flash_attention -> _flash_attention_forward_kernel launch
+ *           (kernels/triton/flash_attention_kernels.py:1291-1310; kernel :38-325) and
+ *           triton_ring_attention_forward -> _ring_attention_forward_kernel launch
+ *           (kernels/triton/attention_kernels.py:979-995; kernel :35-202).
+ *
+ * q [B,Sq,H,D], k/v [B,Sk,Hkv,D], o [B,Sq,H,D] given by (b, s, h) strides (d stride is 1), so
+ * both the reference's seq-major [B,S,H,D] (flash) and head-major [B,H,S,D] (ring) layouts are
+ * accepted.  H % Hkv == 0 (GQA: kv head = h / (H/Hkv), flash_attention.py:894-912).
+ * D in [8,128], D % 8 == 0.
+ *
+ * causal: key position (k_offset + j) > query position (q_offset + i) is excluded.  Without a
+ *   user mask excluded blocks are skipped (exact: the reference's -1e9 fill underflows to 0).
+ * mask: kind KEEP_U8 (uint8) or ADD_F32 (float), addressed with 4 element strides
+ *   (b, h, q, k); 0 strides broadcast.
+ * lse (nullable): [B,H,Sq] fp32, natural-log softmax denominator (m + log l of
+ *   flash_attention_kernels.py:308-325).  Rows with no visible key get lse=-inf, o=0.
+ * Ring carry (nullable o_acc): fp32 [B,Sq,H,D] contiguous running output state.
+ *   carry_in != 0: start from (o_acc, lse) instead of empty;  o_acc != NULL: the normalised
+ *   fp32 output is also written to o_acc (and lse must be non-NULL).  `o` may be NULL when
+ *   o_acc is given (intermediate ring steps).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  float* lse;
+  float* o_acc;
+  const void* mask;
+  int64_t q_stride[3]; /* b, s, h */
+  int64_t k_stride[3];
+  int64_t v_stride[3];
+  int64_t o_stride[3];
+  int64_t mask_stride[4]; /* b, h, q, k */
+  int32_t B, Sq, Sk, H, Hkv, D;
+  int32_t dtype;     /* mio_dtype_t */
+  int32_t causal;    /* 0/1 */
+  int32_t mask_kind; /* mio_mask_kind_t */
+  int32_t carry_in;  /* 0/1 */
+  int32_t q_offset, k_offset;
+  float softmax_scale; /* > 0 */
+} mio_fa3_fwd_params_t;
+
+int mio_fa3_fwd(const mio_fa3_fwd_params_t* p, void* stream);
+
+/* Merge two normalised partial attention states over disjoint key sets (ring / split-KV):
+ * o = w_a*o_a + w_b*o_b, lse = logaddexp(lse_a, lse_b), w_x = exp(lse_x - lse).
+ * Restates the (alpha, beta) update of kernels/triton/attention_kernels.py:1573-1585.
+ * o_* fp32 [rows, D] contiguous with rows = B*Sq*H laid out [B,Sq,H]; lse_* fp32 [B,H,Sq].
+ * Result in (o_a, lse_a); if o_out != NULL the merged output is also written there in `dtype`. */
+int mio_attn_merge(float* o_a, float* lse_a, const float* o_b, const float* lse_b, void* o_out,
+                   int32_t B, int32_t Sq, int32_t H, int32_t D, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * y[M,N] = epilogue( x[M,K] @ w[N,K]^T ), bf16/fp16 in, fp32 accumulate on MFMA.
+ *   act != SWIGLU:  y = act(x w^T + bias) (+ residual)
+ *   act == SWIGLU:  y = silu(x w_gate^T + bias_gate) * (x w^T + bias)
+ * This is the GEMM under both FusedMLP stages and the q/k/v/o projections
+ * (F.linear call sites: kernels/mlp/fused_mlp.py:159,176,225,236,265-266,274;
+ *  kernels/attention/flash_attention.py:629-631,654-657).
+ * ldx/ldw/ldy/ldr: row strides in elements (multiples of 8); K % 8 == 0; bias/residual nullable.
+ * ------------------------------------------------------------------------------------------ */
+int mio_gemm_bias_act(const void* x, const void* w, const void* bias, const void* w_gate,
+                      const void* bias_gate, const void* residual, void* y, int64_t M, int32_t N,
+                      int32_t K, int64_t ldx, int64_t ldw, int64_t ldy, int64_t ldr, int32_t act,
+                      int32_t dtype, void* stream);
+
+/* FusedMLP forward: y = fc2(act(fc1(x))) (+ residual).
+ * Replaces: triton_fused_mlp -> _fused_mlp_{gelu,relu,swiglu}_kernel launch
+ *           (kernels/triton/mlp_kernels.py:648-756, launch :711) and FusedMLP._forward_triton's
+ *           fused_mlp_forward call (kernels/mlp/fused_mlp.py:131-141).
+ * x [M,d], w1/wg [I,d], w2 [d,I], biases nullable; workspace >= mio_fused_mlp_workspace_bytes()
+ * holds the bf16/fp16 [M,I] activation (written once by stage 1's epilogue, read once by stage 2). */
+size_t mio_fused_mlp_workspace_bytes(int64_t M, int32_t d, int32_t I, int32_t act);
+int mio_fused_mlp_fwd(const void* x, const void* w1, const void* b1, const void* wg, const void* bg,
+                      const void* w2, const void* b2, const void* residual, void* y, void* workspace,
+                      int64_t M, int32_t d, int32_t I, int32_t act, int32_t dtype, void* stream);
+
+/* LayerNorm / residual+LayerNorm rows (the step either side of attention):
+ * sum = x + alpha*residual (if residual), y = (sum-mean)/sqrt(var+eps)*weight + bias.
+ * Replaces triton_layernorm -> _layernorm_fwd_kernel / _layernorm_residual_fwd_kernel
+ * (kernels/triton/layernorm_kernels.py:191-276; kernels :35-188).  sum_out nullable. */
+int mio_layernorm_fwd(const void* x, const void* residual, const void* weight, const void* bias,
+                      void* y, void* sum_out, int64_t rows, int32_t cols, float eps, float alpha,
+                      int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Paged-KV decode attention.  Replaces triton_paged_attention_forward ->
+ * _paged_attention_fwd_kernel (kernels/triton/attention_kernels.py:1206-1311; kernel :628-808).
+ * q/o [B,H,q_len,D] (strides b,h,s; d contiguous); caches [num_blocks, L, block_size, Hkv, D]
+ * contiguous; block_tables [B,max_blocks] int32; context_lengths [B] int32.  No causal mask
+ * (the reference's is commented out, :774-776).  workspace: mio_fa3_decode_workspace_bytes().
+ * ------------------------------------------------------------------------------------------ */
+size_t mio_fa3_decode_workspace_bytes(int32_t B, int32_t H, int32_t q_len, int32_t D, int32_t max_ctx);
+int mio_fa3_decode_paged(const void* q, void* o, const void* k_cache, const void* v_cache,
+                         const int32_t* block_tables, const int32_t* context_lengths,
+                         const int64_t q_stride[3], const int64_t o_stride[3], int32_t B, int32_t H,
+                         int32_t Hkv, int32_t q_len, int32_t D, int32_t num_layers, int32_t layer_idx,
+                         int32_t block_size, int32_t max_blocks_per_seq, int32_t max_ctx, float scale,
+                         int32_t dtype, void* workspace, void* stream);
+
+/* Scatter the current token's K/V into the paged cache at position context_len-1.
+ * Replaces triton_reshape_and_cache -> _reshape_and_cache_kernel
+ * (kernels/triton/attention_kernels.py:1314-1407; kernel :811-905).  key/value [B,1,Hkv,D]. */
+int mio_reshape_and_cache(const void* key, const void* value, void* k_cache, void* v_cache,
+                          const int32_t* block_tables, const int32_t* context_lengths,
+                          const int64_t k_stride[2], const int64_t v_stride[2], /* b, h */
+                          int32_t B, int32_t Hkv, int32_t D, int32_t num_layers, int32_t layer_idx,
+                          int32_t block_size, int32_t max_blocks_per_seq, int32_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIO_HIP_H */

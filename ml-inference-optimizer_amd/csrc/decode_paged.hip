@@ -1,0 +1,246 @@
+// Paged-KV decode attention + cache scatter for CDNA4 (gfx950).  HBM-bandwidth-bound: K/V rows go
+// straight from global memory to VGPRs (16 B per lane), no LDS staging, split over the context so
+// a small batch still fills 256 CUs; partial (o, lse) states are merged by a second tiny kernel.
+//
+// Replaces _paged_attention_fwd_kernel (reference kernels/triton/attention_kernels.py:628-808, wrapper
+// :1206-1311) and _reshape_and_cache_kernel (:811-905, wrapper :1314-1407).
+// Cache layout [num_blocks, num_layers, block_size, Hkv, D]; token t of sequence b lives in physical
+// block block_tables[b, t / block_size] at slot t % block_size (:728-751).
+#include "mio_common.h"
+
+struct DecDev {
+  const void* q;
+  void* o;
+  const void* kc;
+  const void* vc;
+  const int32_t* bt;
+  const int32_t* cl;
+  float* ws_o;    // [rows, nsplit, D]
+  float* ws_lse;  // [rows, nsplit]
+  int64_t qs_b, qs_h, qs_s, os_b, os_h, os_s;
+  int B, H, Hkv, q_len, D, L, layer, bs, max_blocks, nsplit, split_len;
+  float scale;
+};
+
+static inline int dec_nsplit(int B, int H, int q_len, int max_ctx) {
+  const int64_t rows = (int64_t)B * H * q_len;
+  int want = (int)((1024 + rows - 1) / rows);
+  int cap = (max_ctx + 255) / 256;
+  if (cap < 1) cap = 1;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  return want;
+}
+
+// CPRP = chunks-per-row padded to a power of two (8 for D <= 64, 16 for D <= 128)
+template <typename T, int CPRP>
+__global__ __launch_bounds__(256) void decode_paged_kernel(const DecDev p) {
+  constexpr int TPI = 64 / CPRP;  // tokens per wave-iteration
+  constexpr int NSTATE = 4 * TPI;
+  __shared__ float s_o[NSTATE][CPRP * 8 + 1];
+  __shared__ float s_m[NSTATE], s_l[NSTATE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = lane / CPRP, c = lane % CPRP;
+  const int row = blockIdx.x;  // (b, h, qi)
+  const int split = blockIdx.y;
+  const int qi = row % p.q_len;
+  const int h = (row / p.q_len) % p.H;
+  const int b = row / (p.q_len * p.H);
+  const int kvh = h / (p.H / p.Hkv);
+  const int ctx = p.cl[b];
+  const int begin = split * p.split_len;
+  int end = begin + p.split_len;
+  if (end > ctx) end = ctx;
+  const bool c_ok = (8 * c < p.D);
+
+  float qf[8];
+  {
+    u32x4_t raw = {0, 0, 0, 0};
+    if (c_ok) raw = *(const u32x4_t*)((const T*)p.q + b * p.qs_b + h * p.qs_h + (int64_t)qi * p.qs_s + 8 * c);
+    const typename DT<T>::x8 v = __builtin_bit_cast(typename DT<T>::x8, raw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qf[i] = (float)v[i] * p.scale;
+  }
+
+  float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = 0.f;
+
+  const int64_t tok_stride = (int64_t)p.Hkv * p.D;
+  const int64_t blk_stride = (int64_t)p.L * p.bs * tok_stride;
+  const int64_t lay_off = (int64_t)p.layer * p.bs * tok_stride + (int64_t)kvh * p.D + 8 * c;
+
+  for (int pos0 = begin + wave * TPI; pos0 < end; pos0 += 4 * TPI) {
+    const int pos = pos0 + t;
+    const bool ok = (pos < end) && c_ok && (pos / p.bs < p.max_blocks);
+    u32x4_t kr = {0, 0, 0, 0}, vr = {0, 0, 0, 0};
+    if (ok) {
+      const int pb = p.bt[(int64_t)b * p.max_blocks + pos / p.bs];
+      const int64_t off = (int64_t)pb * blk_stride + lay_off + (int64_t)(pos % p.bs) * tok_stride;
+      kr = *(const u32x4_t*)((const T*)p.kc + off);
+      vr = *(const u32x4_t*)((const T*)p.vc + off);
+    }
+    const typename DT<T>::x8 kv = __builtin_bit_cast(typename DT<T>::x8, kr);
+    const typename DT<T>::x8 vv = __builtin_bit_cast(typename DT<T>::x8, vr);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += qf[i] * (float)kv[i];
+#pragma unroll
+    for (int x = 1; x < CPRP; x <<= 1) s += __shfl_xor(s, x, 64);
+    if (pos < end) {  // uniform within the token's lane group
+      const float m_new = fmaxf(m, s);
+      const float alpha = __expf(m - m_new);
+      const float pe = __expf(s - m_new);
+      l = l * alpha + pe;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = o[i] * alpha + pe * (float)vv[i];
+      m = m_new;
+    }
+  }
+
+  // ---- merge the NSTATE per-(wave, token-slot) states
+  const int g = wave * TPI + t;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s_o[g][8 * c + i] = o[i];
+  if (c == 0) {
+    s_m[g] = m;
+    s_l[g] = l;
+  }
+  __syncthreads();
+  if (tid < p.D) {
+    float M = -INFINITY;
+    for (int j = 0; j < NSTATE; ++j) M = fmaxf(M, s_m[j]);
+    float Lsum = 0.f, acc = 0.f;
+    if (M != -INFINITY) {
+      for (int j = 0; j < NSTATE; ++j) {
+        const float w = __expf(s_m[j] - M);
+        Lsum += s_l[j] * w;
+        acc += s_o[j][tid] * w;
+      }
+    }
+    const float val = (Lsum > 0.f) ? acc / Lsum : 0.f;  // empty context -> 0 (attention_kernels.py:802)
+    if (p.nsplit == 1) {
+      ((T*)p.o)[b * p.os_b + h * p.os_h + (int64_t)qi * p.os_s + tid] = (T)val;
+    } else {
+      p.ws_o[((int64_t)row * p.nsplit + split) * p.D + tid] = val;
+      if (tid == 0) p.ws_lse[(int64_t)row * p.nsplit + split] = (Lsum > 0.f) ? M + __logf(Lsum) : -INFINITY;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void decode_reduce_kernel(const DecDev p) {
+  const int row = blockIdx.x, d = threadIdx.x;
+  if (d >= p.D) return;
+  const int qi = row % p.q_len;
+  const int h = (row / p.q_len) % p.H;
+  const int b = row / (p.q_len * p.H);
+  float M = -INFINITY;
+  for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, p.ws_lse[(int64_t)row * p.nsplit + s]);
+  float W = 0.f, acc = 0.f;
+  if (M != -INFINITY) {
+    for (int s = 0; s < p.nsplit; ++s) {
+      const float w = __expf(p.ws_lse[(int64_t)row * p.nsplit + s] - M);
+      W += w;
+      acc += w * p.ws_o[((int64_t)row * p.nsplit + s) * p.D + d];
+    }
+  }
+  ((T*)p.o)[b * p.os_b + h * p.os_h + (int64_t)qi * p.os_s + d] = (T)((W > 0.f) ? acc / W : 0.f);
+}
+
+extern "C" size_t mio_fa3_decode_workspace_bytes(int32_t B, int32_t H, int32_t q_len, int32_t D, int32_t max_ctx) {
+  const int ns = dec_nsplit(B, H, q_len, max_ctx);
+  return (size_t)B * H * q_len * ns * (size_t)(D + 1) * sizeof(float) + 256;
+}
+
+extern "C" int mio_fa3_decode_paged(const void* q, void* o, const void* k_cache, const void* v_cache,
+                                    const int32_t* block_tables, const int32_t* context_lengths,
+                                    const int64_t q_stride[3], const int64_t o_stride[3], int32_t B, int32_t H,
+                                    int32_t Hkv, int32_t q_len, int32_t D, int32_t num_layers, int32_t layer_idx,
+                                    int32_t block_size, int32_t max_blocks_per_seq, int32_t max_ctx, float scale,
+                                    int32_t dtype, void* workspace, void* stream) {
+  MIO_CHECK(q && o && k_cache && v_cache && block_tables && context_lengths, "mio_fa3_decode_paged: null pointer");
+  MIO_CHECK(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && q_len > 0, "mio_fa3_decode_paged: bad sizes");
+  MIO_CHECK(D >= 8 && D <= 128 && D % 8 == 0, "mio_fa3_decode_paged: head_dim must be a multiple of 8 in [8,128]");
+  MIO_CHECK(layer_idx >= 0 && layer_idx < num_layers, "mio_fa3_decode_paged: layer_idx out of range");
+  MIO_CHECK(block_size > 0 && max_blocks_per_seq > 0 && max_ctx >= 0, "mio_fa3_decode_paged: bad cache geometry");
+  MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_fa3_decode_paged: dtype must be bf16 or fp16");
+  MIO_CHECK(q_stride[0] % 8 == 0 && q_stride[1] % 8 == 0 && q_stride[2] % 8 == 0 && mio_aligned16(q) &&
+                mio_aligned16(k_cache) && mio_aligned16(v_cache),
+            "mio_fa3_decode_paged: q/cache rows must be 16-byte aligned");
+  DecDev p;
+  p.q = q; p.o = o; p.kc = k_cache; p.vc = v_cache; p.bt = block_tables; p.cl = context_lengths;
+  p.qs_b = q_stride[0]; p.qs_h = q_stride[1]; p.qs_s = q_stride[2];
+  p.os_b = o_stride[0]; p.os_h = o_stride[1]; p.os_s = o_stride[2];
+  p.B = B; p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.D = D; p.L = num_layers; p.layer = layer_idx;
+  p.bs = block_size; p.max_blocks = max_blocks_per_seq; p.scale = scale;
+  p.nsplit = dec_nsplit(B, H, q_len, max_ctx);
+  int sl = (max_ctx + p.nsplit - 1) / p.nsplit;
+  sl = (sl + 31) / 32 * 32;
+  if (sl < 32) sl = 32;
+  p.split_len = sl;
+  MIO_CHECK(p.nsplit == 1 || workspace != nullptr, "mio_fa3_decode_paged: workspace required");
+  const int64_t rows = (int64_t)B * H * q_len;
+  p.ws_o = (float*)workspace;
+  p.ws_lse = p.ws_o ? p.ws_o + rows * p.nsplit * D : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)rows, (unsigned)p.nsplit), block(256);
+  if (dtype == MIO_BF16) {
+    if (D <= 64) hipLaunchKernelGGL((decode_paged_kernel<__bf16, 8>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((decode_paged_kernel<__bf16, 16>), grid, block, 0, st, p);
+    if (p.nsplit > 1) hipLaunchKernelGGL(decode_reduce_kernel<__bf16>, dim3((unsigned)rows), dim3(128), 0, st, p);
+  } else {
+    if (D <= 64) hipLaunchKernelGGL((decode_paged_kernel<_Float16, 8>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((decode_paged_kernel<_Float16, 16>), grid, block, 0, st, p);
+    if (p.nsplit > 1) hipLaunchKernelGGL(decode_reduce_kernel<_Float16>, dim3((unsigned)rows), dim3(128), 0, st, p);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("decode_paged launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+// ---- reshape_and_cache: one workgroup per sequence, 16-byte chunks over (Hkv, D) --------------------
+__global__ __launch_bounds__(256) void reshape_and_cache_kernel(const uint16_t* __restrict__ key,
+                                                                const uint16_t* __restrict__ value,
+                                                                uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
+                                                                const int32_t* __restrict__ bt,
+                                                                const int32_t* __restrict__ cl, int64_t ks_b,
+                                                                int64_t ks_h, int64_t vs_b, int64_t vs_h, int Hkv,
+                                                                int D, int L, int layer, int bs, int max_blocks) {
+  const int b = blockIdx.x;
+  const int pos = cl[b] - 1;  // write position (attention_kernels.py:858)
+  if (pos < 0) return;
+  const int pb = bt[(int64_t)b * max_blocks + pos / bs];
+  const int64_t tok_stride = (int64_t)Hkv * D;
+  const int64_t dst = ((int64_t)pb * L + layer) * bs * tok_stride + (int64_t)(pos % bs) * tok_stride;
+  const int cpr = D >> 3;
+  for (int i = threadIdx.x; i < Hkv * cpr; i += 256) {
+    const int hh = i / cpr, c = i % cpr;
+    const u32x4_t kk = *(const u32x4_t*)(key + b * ks_b + hh * ks_h + 8 * c);
+    const u32x4_t vv = *(const u32x4_t*)(value + b * vs_b + hh * vs_h + 8 * c);
+    *(u32x4_t*)(kc + dst + (int64_t)hh * D + 8 * c) = kk;
+    *(u32x4_t*)(vc + dst + (int64_t)hh * D + 8 * c) = vv;
+  }
+}
+
+extern "C" int mio_reshape_and_cache(const void* key, const void* value, void* k_cache, void* v_cache,
+                                     const int32_t* block_tables, const int32_t* context_lengths,
+                                     const int64_t k_stride[2], const int64_t v_stride[2], int32_t B, int32_t Hkv,
+                                     int32_t D, int32_t num_layers, int32_t layer_idx, int32_t block_size,
+                                     int32_t max_blocks_per_seq, int32_t dtype, void* stream) {
+  MIO_CHECK(key && value && k_cache && v_cache && block_tables && context_lengths, "mio_reshape_and_cache: null pointer");
+  MIO_CHECK(B > 0 && Hkv > 0 && D >= 8 && D % 8 == 0, "mio_reshape_and_cache: bad sizes");
+  MIO_CHECK(layer_idx >= 0 && layer_idx < num_layers && block_size > 0, "mio_reshape_and_cache: bad cache geometry");
+  MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_reshape_and_cache: dtype must be bf16 or fp16");
+  MIO_CHECK(k_stride[0] % 8 == 0 && k_stride[1] % 8 == 0 && v_stride[0] % 8 == 0 && v_stride[1] % 8 == 0 &&
+                mio_aligned16(key) && mio_aligned16(value) && mio_aligned16(k_cache) && mio_aligned16(v_cache),
+            "mio_reshape_and_cache: 16-byte alignment");
+  hipLaunchKernelGGL(reshape_and_cache_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)key, (const uint16_t*)value, (uint16_t*)k_cache, (uint16_t*)v_cache,
+                     block_tables, context_lengths, k_stride[0], k_stride[1], v_stride[0], v_stride[1], Hkv, D,
+                     num_layers, layer_idx, block_size, max_blocks_per_seq);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("reshape_and_cache launch: ") + hipGetErrorString(e));
+  return 0;
+}

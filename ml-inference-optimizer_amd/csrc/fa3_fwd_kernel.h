@@ -1,0 +1,357 @@
+// FlashAttention-3 style prefill kernel for CDNA4 (gfx950), written for 64-wide wavefronts.
+//
+// Replaces _flash_attention_forward_kernel (reference kernels/triton/flash_attention_kernels.py:38-325)
+// and _ring_attention_forward_kernel (kernels/triton/attention_kernels.py:35-202).
+//
+// Structure (one workgroup = 4 waves = 128 query rows of one (batch, head); KV tile = 64 keys):
+//   * Q fragments live in registers for the whole kernel (B operand of the QK^T MFMA).
+//   * K/V tiles are staged global -> registers -> LDS, double buffered; the global loads of tile
+//     t+1 are issued before the MFMA work of tile t and written to LDS after it (issue-early /
+//     write-late), one barrier per tile.
+//   * "Swapped" QK^T:  S^T[key][query] = K . Q^T with v_mfma_f32_32x32x16.  The accumulator then
+//     has the QUERY on the lane (col = lane&31) and 16 keys in registers, so the row max / row sum
+//     are in-register reductions plus ONE cross-half exchange (v_permlane32_swap), and the
+//     softmax'd tile is already the B operand of the next MFMA:
+//   * O^T[d][query] += V^T[d][key] . P^T[key][query].  P^T needs no LDS round trip or lane
+//     shuffle (accumulator registers 8s..8s+7 -> bf16 = the k-step-s fragment); V^T fragments come
+//     from a row-major V tile through the hardware transposing read ds_read_b64_tr_b16.
+//     The running (m, l) are per-lane scalars in the same layout, so the rescale is lane-local.
+//   * LDS images: K rows padded by 16 B (conflict-free ds_read_b128 for any D), V as
+//     [key/8][d/32][8][32] sub-tiles (each half-wave's transposed read covers one 256-B bank row).
+#pragma once
+#include "mio_common.h"
+
+struct FaDev {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  float* lse;
+  float* o_acc;
+  const void* mask;
+  int64_t qs_b, qs_s, qs_h;
+  int64_t ks_b, ks_s, ks_h;
+  int64_t vs_b, vs_s, vs_h;
+  int64_t os_b, os_s, os_h;
+  int64_t ms_b, ms_h, ms_q, ms_k;
+  int B, Sq, Sk, H, Hkv, D;
+  int carry_in, q_offset, k_offset;
+  int nqblk, xcd_remap;
+  float scale_log2e;  // softmax_scale * log2(e)
+};
+
+constexpr int FA_BM = 128;
+constexpr int FA_BN = 64;
+constexpr float FA_LOG2E = 1.4426950408889634f;
+constexpr float FA_LN2 = 0.6931471805599453f;
+constexpr float FA_NEG_FILL_LOG2 = -1.0e9f * FA_LOG2E;  // the reference's -1e9 fill, in the exp2 domain
+
+template <int D>
+struct FaSmem {
+  static constexpr int KROW = D * 2 + 16;       // bytes per K row (padded)
+  static constexpr int K_BYTES = FA_BN * KROW;
+  static constexpr int V_BYTES = FA_BN * D * 2;
+  static constexpr int STAGE = K_BYTES + V_BYTES;
+  static constexpr int TOTAL = 2 * STAGE;
+};
+
+template <typename T, int D, bool CAUSAL, int MASK>
+__global__ __launch_bounds__(256) void fa3_fwd_kernel(const FaDev p) {
+  using X8 = typename DT<T>::x8;
+  using X4 = typename DT<T>::x4;
+  using SM = FaSmem<D>;
+  constexpr int KS = D / 16;       // k-steps of the QK^T product
+  constexpr int DT_ = D / 32;      // 32-row d tiles of O^T
+  constexpr int CPR = D / 8;       // 16-byte chunks per K/V row
+  constexpr int NLD = D / 32;      // chunks per thread per operand per tile
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- workgroup -> (batch, head, query block); same (b,h) stays on one XCD for K/V reuse in L2
+  int bh, qi;
+  {
+    const int id = blockIdx.x;
+    if (p.xcd_remap) {
+      const int xcd = id & 7, slot = id >> 3;
+      bh = (slot / p.nqblk) * 8 + xcd;
+      qi = slot % p.nqblk;
+    } else {
+      bh = id / p.nqblk;
+      qi = id % p.nqblk;
+    }
+  }
+  const int qblk = CAUSAL ? (p.nqblk - 1 - qi) : qi;  // heaviest causal blocks first
+  const int b = bh / p.H, head = bh % p.H;
+  const int kvh = head / (p.H / p.Hkv);
+  const int q0 = qblk * FA_BM;
+  const int qrow = q0 + wave * 32 + r;
+  const bool q_ok = qrow < p.Sq;
+
+  // ---- Q fragments (B operand: lane (r,h) holds Q[qrow][16ks + 8h .. +7])
+  X8 qf[KS];
+  {
+    const T* qp = (const T*)p.q + b * p.qs_b + head * p.qs_h + (int64_t)qrow * p.qs_s;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = 16 * ks + 8 * h;
+      u32x4_t raw = {0, 0, 0, 0};
+      if (q_ok && d0 < p.D) raw = *(const u32x4_t*)(qp + d0);
+      qf[ks] = __builtin_bit_cast(X8, raw);
+    }
+  }
+
+  // ---- running state
+  f32x16_t oacc[DT_];
+  float m_i = -INFINITY, l_i = 0.f;
+#pragma unroll
+  for (int dt = 0; dt < DT_; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
+
+  if (p.carry_in) {
+    if (q_ok) {
+      const float lse_in = p.lse[((int64_t)b * p.H + head) * p.Sq + qrow];
+      if (lse_in != -INFINITY) {
+        m_i = lse_in * FA_LOG2E;
+        l_i = (h == 0) ? 1.f : 0.f;
+      }
+      const float* oa = p.o_acc + (((int64_t)b * p.Sq + qrow) * p.H + head) * p.D;
+#pragma unroll
+      for (int dt = 0; dt < DT_; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = 32 * dt + 8 * g + 4 * h;
+          if (d0 < p.D) {
+            const f32x4_t x = *(const f32x4_t*)(oa + d0);
+            oacc[dt][4 * g + 0] = x[0];
+            oacc[dt][4 * g + 1] = x[1];
+            oacc[dt][4 * g + 2] = x[2];
+            oacc[dt][4 * g + 3] = x[3];
+          }
+        }
+    }
+  }
+
+  // ---- number of KV tiles this workgroup visits
+  int n_tiles;
+  if (CAUSAL && MASK == 0) {
+    int kmax = q0 + FA_BM - 1 + p.q_offset - p.k_offset;
+    if (kmax > p.Sk - 1) kmax = p.Sk - 1;
+    n_tiles = kmax < 0 ? 0 : kmax / FA_BN + 1;
+  } else {
+    n_tiles = (p.Sk + FA_BN - 1) / FA_BN;
+  }
+
+  // ---- staging helpers
+  const T* kbase = (const T*)p.k + b * p.ks_b + kvh * p.ks_h;
+  const T* vbase = (const T*)p.v + b * p.vs_b + kvh * p.vs_h;
+  u32x4_t kreg[NLD], vreg[NLD];
+
+  auto stage_load = [&](int tile) {
+    const int kv0 = tile * FA_BN;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int i = tid + 256 * j;
+      const int row = i / CPR, c = i % CPR;
+      const int kv = kv0 + row;
+      const bool ok = (kv < p.Sk) && (8 * c < p.D);
+      u32x4_t zk = {0, 0, 0, 0}, zv = {0, 0, 0, 0};
+      if (ok) {
+        zk = *(const u32x4_t*)(kbase + (int64_t)kv * p.ks_s + 8 * c);
+        zv = *(const u32x4_t*)(vbase + (int64_t)kv * p.vs_s + 8 * c);
+      }
+      kreg[j] = zk;
+      vreg[j] = zv;
+    }
+  };
+  auto stage_write = [&](int buf) {
+    char* kb = smem + buf * SM::STAGE;
+    char* vb = kb + SM::K_BYTES;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int i = tid + 256 * j;
+      const int row = i / CPR, c = i % CPR;
+      *(u32x4_t*)(kb + row * SM::KROW + 16 * c) = kreg[j];
+      *(u32x4_t*)(vb + ((row >> 3) * DT_ + (c >> 2)) * 512 + (row & 7) * 64 + (c & 3) * 16) = vreg[j];
+    }
+  };
+
+  if (n_tiles > 0) {
+    stage_load(0);
+    stage_write(0);
+  }
+  __syncthreads();
+
+  // per-lane LDS read offsets
+  const int k_rd = r * SM::KROW + 16 * h;                         // + 32*KROW*tt + 32*ks
+  const int g16 = lane >> 4, i16 = lane & 15;                     // transposed-read group / lane in group
+  const int v_rd = (4 * h + (i16 >> 2)) * 64 + 32 * (g16 & 1) + 8 * (i16 & 3);  // + ((2s+u)*DT_ + dt)*512
+  const int q_pos = qrow + p.q_offset;
+  const float c2 = p.scale_log2e;
+
+  for (int t = 0; t < n_tiles; ++t) {
+    const int cur = t & 1;
+    const bool more = (t + 1 < n_tiles);
+    if (more) stage_load(t + 1);
+
+    const int kv0 = t * FA_BN;
+    bool skip = false;
+    if (CAUSAL && MASK == 0) {
+      // every key of this tile is in the future of every row of this wave
+      skip = (kv0 + p.k_offset) > (q0 + wave * 32 + 31 + p.q_offset);
+    }
+    if (!skip) {
+      const char* kb = smem + cur * SM::STAGE;
+      const char* vb = kb + SM::K_BYTES;
+
+      // ---- S^T = K . Q^T   (two 32-key tiles)
+      f32x16_t s0, s1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s0[i] = 0.f;
+        s1[i] = 0.f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const X8 a0 = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + k_rd + 32 * ks));
+        const X8 a1 = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + k_rd + 32 * SM::KROW + 32 * ks));
+        s0 = DT<T>::mfma32(a0, qf[ks], s0);
+        s1 = DT<T>::mfma32(a1, qf[ks], s1);
+      }
+
+      // ---- scores -> exp2 domain, masks
+      float sv[32];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sv[i] = s0[i];
+        sv[16 + i] = s1[i];
+      }
+      float mx;
+      if (MASK == 0) {
+        bool need_causal = false, need_bound = (kv0 + FA_BN > p.Sk);
+        if (CAUSAL) need_causal = (kv0 + FA_BN - 1 + p.k_offset) > (q0 + wave * 32 + p.q_offset);
+        if (need_causal || need_bound) {
+#pragma unroll
+          for (int i = 0; i < 32; ++i) {
+            const int kv = kv0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
+            const bool dead = (kv >= p.Sk) || (CAUSAL && (kv + p.k_offset > q_pos));
+            if (dead) sv[i] = -INFINITY;
+          }
+        }
+        mx = sv[0];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) mx = fmaxf(mx, sv[i]);
+        mx *= c2;
+      } else {
+        const int64_t mrow = (int64_t)b * p.ms_b + (int64_t)head * p.ms_h + (int64_t)(q_ok ? qrow : 0) * p.ms_q;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const int kv = kv0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
+          float tv = sv[i] * c2;
+          if (CAUSAL && (kv + p.k_offset > q_pos)) tv = FA_NEG_FILL_LOG2;
+          if (kv < p.Sk) {
+            if (MASK == MIO_MASK_KEEP_U8) {
+              const uint8_t keep = ((const uint8_t*)p.mask)[mrow + (int64_t)kv * p.ms_k];
+              if (!keep) tv = FA_NEG_FILL_LOG2;
+            } else {
+              tv += ((const float*)p.mask)[mrow + (int64_t)kv * p.ms_k] * FA_LOG2E;
+            }
+          } else {
+            tv = -INFINITY;
+          }
+          sv[i] = tv;
+        }
+        mx = sv[0];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) mx = fmaxf(mx, sv[i]);
+      }
+      mx = fmaxf(mx, other_half(mx));
+
+      // ---- online softmax update (flash_attention_kernels.py:276-298 with exp -> exp2)
+      const float m_new = fmaxf(m_i, mx);
+      const float m_sub = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = fast_exp2(m_i - m_sub);
+      float rs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const float e = (MASK == 0) ? fast_exp2(__builtin_fmaf(sv[i], c2, -m_sub)) : fast_exp2(sv[i] - m_sub);
+        sv[i] = e;
+        rs += e;
+      }
+      l_i = l_i * alpha + rs;
+      m_i = m_new;
+#pragma unroll
+      for (int dt = 0; dt < DT_; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+
+      // ---- P^T fragments: k-step s (16 keys) = accumulator registers 8(s&1)..+7 of tile s>>1
+      X8 pf[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        u32x4_t w;
+        w[0] = pack2<T>(sv[8 * s + 0], sv[8 * s + 1]);
+        w[1] = pack2<T>(sv[8 * s + 2], sv[8 * s + 3]);
+        w[2] = pack2<T>(sv[8 * s + 4], sv[8 * s + 5]);
+        w[3] = pack2<T>(sv[8 * s + 6], sv[8 * s + 7]);
+        pf[s] = __builtin_bit_cast(X8, w);
+      }
+
+      // ---- O^T += V^T . P^T
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int dt = 0; dt < DT_; ++dt) {
+          const X4 lo = DT<T>::ds_read_tr(vb + v_rd + ((2 * s + 0) * DT_ + dt) * 512);
+          const X4 hi = DT<T>::ds_read_tr(vb + v_rd + ((2 * s + 1) * DT_ + dt) * 512);
+          X8 vf;
+          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+          vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+          oacc[dt] = DT<T>::mfma32(vf, pf[s], oacc[dt]);
+        }
+      }
+    }
+
+    if (more) stage_write(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: normalise, write O (and the fp32 carry state / lse)
+  const float l_tot = l_i + other_half(l_i);
+  const float inv = (l_tot > 0.f) ? fast_rcp(l_tot) : 0.f;
+  if (q_ok) {
+    if (p.lse != nullptr && h == 0) {
+      const float lse = (l_tot > 0.f) ? (m_i + fast_log2(l_tot)) * FA_LN2 : -INFINITY;
+      p.lse[((int64_t)b * p.H + head) * p.Sq + qrow] = lse;
+    }
+    T* op = (p.o != nullptr) ? ((T*)p.o + b * p.os_b + head * p.os_h + (int64_t)qrow * p.os_s) : nullptr;
+    float* oa = (p.o_acc != nullptr) ? (p.o_acc + (((int64_t)b * p.Sq + qrow) * p.H + head) * p.D) : nullptr;
+#pragma unroll
+    for (int dt = 0; dt < DT_; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 32 * dt + 8 * g + 4 * h;
+        if (d0 < p.D) {
+          const float x0 = oacc[dt][4 * g + 0] * inv, x1 = oacc[dt][4 * g + 1] * inv;
+          const float x2 = oacc[dt][4 * g + 2] * inv, x3 = oacc[dt][4 * g + 3] * inv;
+          if (op != nullptr) {
+            u32x2_t w = {pack2<T>(x0, x1), pack2<T>(x2, x3)};
+            *(u32x2_t*)(op + d0) = w;
+          }
+          if (oa != nullptr) {
+            f32x4_t w = {x0, x1, x2, x3};
+            *(f32x4_t*)(oa + d0) = w;
+          }
+        }
+      }
+  }
+}
+
+// Host launcher for one (dtype, padded D); defined per translation unit (fa3_fwd_inst.hip).
+template <typename T, int D>
+int fa3_launch(const FaDev& p, int causal, int mask_kind, hipStream_t stream);

@@ -1,0 +1,424 @@
+"""Functional entry points of the hot path: thin argument checking + one C-ABI call each.
+
+These mirror the reference's functional launch wrappers (same positional/keyword signatures,
+same exception types for the same conditions):
+  flash_attention           <- triton_flash_attention        (kernels/triton/flash_attention_kernels.py:1150-1358)
+  ring_attention_forward    <- triton_ring_attention_forward (kernels/triton/attention_kernels.py:909-1005)
+  fused_mlp                 <- triton_fused_mlp              (kernels/triton/mlp_kernels.py:648-756)
+  layernorm                 <- triton_layernorm              (kernels/triton/layernorm_kernels.py:191-276)
+  paged_attention_forward   <- triton_paged_attention_forward(kernels/triton/attention_kernels.py:1206-1311)
+  reshape_and_cache         <- triton_reshape_and_cache      (kernels/triton/attention_kernels.py:1314-1407)
+There is no fallback path: a non-zero return from the library raises RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+_ACT = {
+    "none": _lib.ACT_NONE,
+    "gelu": _lib.ACT_GELU_TANH,       # the Triton kernel's GELU is the tanh form (mlp_kernels.py:144-161)
+    "gelu_tanh": _lib.ACT_GELU_TANH,
+    "gelu_new": _lib.ACT_GELU_TANH,
+    "gelu_erf": _lib.ACT_GELU_ERF,
+    "relu": _lib.ACT_RELU,
+    "silu": _lib.ACT_SILU,
+    "swish": _lib.ACT_SILU,
+    "swiglu": _lib.ACT_SWIGLU,
+}
+
+
+def _dtype_id(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return _lib.MIO_BF16
+    if t.dtype == torch.float16:
+        return _lib.MIO_FP16
+    raise ValueError(f"HIP kernels compute in bf16 or fp16, got {t.dtype}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts: Optional[torch.Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("HIP kernels require input tensors to be on a CUDA (ROCm) device.")
+
+
+def _rows16(t: torch.Tensor) -> torch.Tensor:
+    """Make the last dim contiguous and every other stride a multiple of 8 elements."""
+    if t.stride(-1) != 1 or any(s % 8 for s in t.stride()[:-1]) or t.data_ptr() % 16:
+        return t.contiguous()
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def fa3_fwd(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    *,
+    layout: str = "bshd",
+    causal: bool = False,
+    softmax_scale: Optional[float] = None,
+    keep_mask: Optional[torch.Tensor] = None,
+    additive_mask: Optional[torch.Tensor] = None,
+    return_lse: bool = False,
+    out: Optional[torch.Tensor] = None,
+    o_acc: Optional[torch.Tensor] = None,
+    lse: Optional[torch.Tensor] = None,
+    carry_in: bool = False,
+    write_out: bool = True,
+    q_offset: int = 0,
+    k_offset: int = 0,
+):
+    """One launch of the tiled attention kernel.
+
+    layout "bshd": q [B,Sq,H,D], k/v [B,Sk,Hkv,D] (flash); "bhsd": head-major (ring, a9).
+    keep_mask / additive_mask: 4-D, broadcastable to [B,H,Sq,Sk] (size-1 dims broadcast).
+    Ring carry: o_acc fp32 [B,Sq,H,D] + lse fp32 [B,H,Sq]; carry_in continues from that state.
+    Returns out (same layout as q) or (out, lse) if return_lse.
+    """
+    _need_cuda(q, k, v)
+    if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
+        raise ValueError(f"Expected 4D tensors for q, k, v but got shapes: q={q.shape}, k={k.shape}, v={v.shape}")
+    if layout not in ("bshd", "bhsd"):
+        raise ValueError(f"unknown layout {layout}")
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        raise ValueError("q, k, v must have the same dtype")
+    dt = _dtype_id(q)
+    q, k, v = _rows16(q), _rows16(k), _rows16(v)
+    si, hi = (1, 2) if layout == "bshd" else (2, 1)
+    B, Sq, H, D = q.shape[0], q.shape[si], q.shape[hi], q.shape[3]
+    Sk, Hkv = k.shape[si], k.shape[hi]
+    if k.shape[0] != B or v.shape != k.shape or k.shape[3] != D:
+        raise ValueError(f"incompatible q/k/v shapes: q={q.shape}, k={k.shape}, v={v.shape}")
+    if H % Hkv != 0:
+        raise ValueError(f"num_heads {H} must be a multiple of num_kv_heads {Hkv}")
+    if D % 8 != 0 or D > 128:
+        raise ValueError(f"head_dim must be a multiple of 8 and <= 128, got {D}")
+    scale = (1.0 / math.sqrt(D)) if softmax_scale is None else float(softmax_scale)
+    if not (scale > 0.0):
+        raise ValueError("softmax_scale must be positive")
+    if keep_mask is not None and additive_mask is not None:
+        raise ValueError("give either keep_mask or additive_mask, not both")
+
+    p = _lib.FaParams()
+    if write_out:
+        if out is None:
+            out = torch.empty_like(q, memory_format=torch.contiguous_format)
+        elif out.shape != q.shape or out.dtype != q.dtype or out.stride(-1) != 1:
+            raise ValueError("out must match q in shape/dtype with a contiguous last dim")
+    else:
+        out = None
+        if o_acc is None:
+            raise ValueError("write_out=False needs o_acc")
+    if o_acc is not None:
+        if o_acc.dtype != torch.float32 or tuple(o_acc.shape) != (B, Sq, H, D) or not o_acc.is_contiguous():
+            raise ValueError("o_acc must be contiguous fp32 [B,Sq,H,D]")
+        if lse is None:
+            raise ValueError("o_acc needs an lse buffer")
+    if (return_lse or o_acc is not None) and lse is None:
+        lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
+    if lse is not None and (lse.dtype != torch.float32 or tuple(lse.shape) != (B, H, Sq) or not lse.is_contiguous()):
+        raise ValueError("lse must be contiguous fp32 [B,H,Sq]")
+    if carry_in and o_acc is None:
+        raise ValueError("carry_in needs o_acc and lse")
+
+    mask, kind = None, _lib.MASK_NONE
+    if keep_mask is not None:
+        mask, kind = keep_mask, _lib.MASK_KEEP_U8
+        if mask.dtype != torch.uint8:
+            mask = (mask != 0).to(torch.uint8)
+    elif additive_mask is not None:
+        mask, kind = additive_mask.to(torch.float32), _lib.MASK_ADD_F32
+    if mask is not None:
+        _need_cuda(mask)
+        if mask.dim() != 4:
+            raise ValueError(f"Unsupported mask shape: {tuple(mask.shape)}")
+        for dim, full in zip(mask.shape, (B, H, Sq, Sk)):
+            if dim not in (1, full):
+                raise ValueError(f"mask shape {tuple(mask.shape)} does not broadcast to {(B, H, Sq, Sk)}")
+        for i in range(4):
+            p.mask_stride[i] = 0 if mask.shape[i] == 1 else mask.stride(i)
+
+    def _st(dst, t):
+        dst[0], dst[1], dst[2] = t.stride(0), t.stride(si), t.stride(hi)
+
+    _st(p.q_stride, q)
+    _st(p.k_stride, k)
+    _st(p.v_stride, v)
+    if out is not None:
+        _st(p.o_stride, out)
+    p.q, p.k, p.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+    p.o, p.lse, p.o_acc, p.mask = _ptr(out), _ptr(lse), _ptr(o_acc), _ptr(mask)
+    p.B, p.Sq, p.Sk, p.H, p.Hkv, p.D = B, Sq, Sk, H, Hkv, D
+    p.dtype, p.causal, p.mask_kind, p.carry_in = dt, int(bool(causal)), kind, int(bool(carry_in))
+    p.q_offset, p.k_offset, p.softmax_scale = int(q_offset), int(k_offset), scale
+    check(lib.mio_fa3_fwd(C.byref(p), _stream()))
+    if return_lse:
+        return out, lse
+    return out
+
+
+def _canon_mask4(mask: torch.Tensor) -> torch.Tensor:
+    """[B,S] / [B,1,S] / [B,S,S] / 4-D -> 4-D, as flash_attention_kernels.py:1232-1250."""
+    if mask.dim() == 2:
+        return mask[:, None, None, :]
+    if mask.dim() == 3:
+        return mask[:, :, None, :] if mask.shape[1] == 1 else mask[:, None, :, :]
+    if mask.dim() == 4:
+        return mask
+    raise ValueError(f"Unsupported mask shape: {mask.shape}")
+
+
+def flash_attention(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    mask: Optional[torch.Tensor] = None,
+    causal: bool = False,
+    softmax_scale: Optional[float] = None,
+    dropout_p: float = 0.0,
+    return_softmax: bool = False,
+    block_size: int = 128,
+):
+    """Drop-in for triton_flash_attention (flash_attention_kernels.py:1150-1358), q/k/v [B,S,H,D].
+
+    mask: keep-mask (nonzero = attend; masked scores := -1e9, :257-273) of shape [B,S], [B,1,S],
+    [B,S,S] or 4-D.  block_size is accepted for signature compatibility; the HIP kernel's tile
+    (128 queries x 64 keys) is fixed.  return_softmax / dropout_p > 0 are not computed by the
+    fused kernel: NotImplementedError (the reference's autograd path punts the same way, :1044-1046).
+    """
+    if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
+        raise ValueError(f"Expected 4D tensors for q, k, v but got shapes: q={q.shape}, k={k.shape}, v={v.shape}")
+    if return_softmax:
+        raise NotImplementedError("return_softmax=True is not supported by the fused HIP kernel")
+    if dropout_p and dropout_p > 0.0:
+        raise NotImplementedError("attention dropout (training) is not supported by the inference kernel")
+    keep = None
+    if mask is not None:
+        keep = _canon_mask4(mask.to(q.device))
+    return fa3_fwd(q, k, v, layout="bshd", causal=causal, softmax_scale=softmax_scale, keep_mask=keep)
+
+
+def ring_attention_forward(
+    query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attention_mask: Optional[torch.Tensor] = None
+) -> torch.Tensor:
+    """Drop-in for triton_ring_attention_forward (attention_kernels.py:909-1005; fallback :1520-1591):
+    q/k/v [B,H,S,D] head-major, additive mask [B,1|H,Sq,Sk]; returns [B,Sq,H*D]."""
+    if query.dim() != 4:
+        raise ValueError(f"Expected 4D tensors, got {query.shape}")
+    B, H, Sq, D = query.shape
+    out = torch.empty(B, Sq, H, D, dtype=query.dtype, device=query.device)
+    # write straight into the [B,Sq,H*D] result: give the kernel a head-major VIEW of it
+    fa3_fwd(query, key, value, layout="bhsd", additive_mask=attention_mask, out=out.permute(0, 2, 1, 3))
+    return out.view(B, Sq, H * D)
+
+
+def attn_merge(o_a, lse_a, o_b, lse_b, out: Optional[torch.Tensor] = None):
+    """(o_a, lse_a) <- merge((o_a, lse_a), (o_b, lse_b)); fp32 states [B,Sq,H,D] / [B,H,Sq]."""
+    _need_cuda(o_a, lse_a, o_b, lse_b)
+    B, Sq, H, D = o_a.shape
+    for t in (o_a, o_b, lse_a, lse_b):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("merge states must be contiguous fp32")
+    dt = _lib.MIO_BF16 if out is None else _dtype_id(out)
+    if out is not None and (tuple(out.shape) != (B, Sq, H, D) or not out.is_contiguous()):
+        raise ValueError("out must be contiguous [B,Sq,H,D]")
+    check(lib.mio_attn_merge(o_a.data_ptr(), lse_a.data_ptr(), o_b.data_ptr(), lse_b.data_ptr(), _ptr(out),
+                             B, Sq, H, D, dt, _stream()))
+    return o_a, lse_a
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM / FusedMLP / LayerNorm
+# ------------------------------------------------------------------------------------------------
+def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_gate=None, residual=None, out=None):
+    """y = act(x @ w^T + bias) (+ residual); x [..., K], w [N, K].  F.linear with a fused epilogue."""
+    _need_cuda(x, w)
+    if activation not in _ACT:
+        raise ValueError(f"Unsupported activation function: {activation}")
+    act = _ACT[activation]
+    dt = _dtype_id(x)
+    if w.dtype != x.dtype:
+        raise ValueError("x and w must have the same dtype")
+    K = x.shape[-1]
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"weight shape {tuple(w.shape)} does not match input features {K}")
+    x2 = x.reshape(-1, K)
+    x2, w = _rows16(x2), _rows16(w)
+    M = x2.shape[0]
+    if act == _lib.ACT_SWIGLU:
+        if w_gate is None:
+            raise ValueError("SwiGLU activation requires gate weights")
+        w_gate = _rows16(w_gate)
+    else:
+        w_gate, bias_gate = None, None
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    y2 = out.view(-1, N)
+    r2 = None
+    if residual is not None:
+        r2 = _rows16(residual.reshape(-1, N))
+    for b_ in (bias, bias_gate):
+        if b_ is not None and (b_.dtype != x.dtype or not b_.is_contiguous()):
+            raise ValueError("bias must be contiguous and of the input dtype")
+    check(lib.mio_gemm_bias_act(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(w_gate), _ptr(bias_gate), _ptr(r2),
+                                y2.data_ptr(), M, N, K, x2.stride(0), w.stride(0), y2.stride(0),
+                                0 if r2 is None else r2.stride(0), act, dt, _stream()))
+    return out
+
+
+def fused_mlp(
+    hidden_states: torch.Tensor,
+    fc1_weight: torch.Tensor,
+    fc1_bias: Optional[torch.Tensor],
+    fc2_weight: torch.Tensor,
+    fc2_bias: Optional[torch.Tensor],
+    activation: str = "gelu",
+    fc1_gate_weight: Optional[torch.Tensor] = None,
+    fc1_gate_bias: Optional[torch.Tensor] = None,
+    residual: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Drop-in for triton_fused_mlp (mlp_kernels.py:648-756): fc2(act(fc1(x))), hidden [B,S,d].
+    "gelu" is the tanh form like the Triton kernel (:144-161); "gelu_erf" is pytorch_fused_mlp's (:782-783)."""
+    if hidden_states.dim() != 3:
+        raise ValueError(f"Expected 3D input tensor, got shape: {hidden_states.shape}")
+    _need_cuda(hidden_states)
+    if activation not in _ACT or _ACT[activation] == _lib.ACT_NONE:
+        raise ValueError(f"Unsupported activation function: {activation}")
+    act = _ACT[activation]
+    if act == _lib.ACT_SWIGLU and fc1_gate_weight is None:
+        raise ValueError("SwiGLU activation requires gate weights")
+    dt = _dtype_id(hidden_states)
+    d = hidden_states.shape[-1]
+    I = fc1_weight.shape[0]
+    if fc1_weight.shape[1] != d or tuple(fc2_weight.shape) != (d, I):
+        raise ValueError("fc1/fc2 weight shapes do not match hidden size")
+    x2 = _rows16(hidden_states.reshape(-1, d))
+    if x2.stride(0) != d:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    ws = [fc1_weight, fc2_weight] + ([fc1_gate_weight] if act == _lib.ACT_SWIGLU else [])
+    for w_ in ws:
+        if w_.dtype != hidden_states.dtype or not w_.is_contiguous():
+            raise ValueError("weights must be contiguous and of the input dtype")
+    out = torch.empty_like(hidden_states, memory_format=torch.contiguous_format)
+    work = torch.empty(M, I, dtype=hidden_states.dtype, device=hidden_states.device)
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, d)
+        if not r2.is_contiguous():
+            r2 = r2.contiguous()
+    gate_w = fc1_gate_weight if act == _lib.ACT_SWIGLU else None
+    gate_b = fc1_gate_bias if act == _lib.ACT_SWIGLU else None
+    check(lib.mio_fused_mlp_fwd(x2.data_ptr(), fc1_weight.data_ptr(), _ptr(fc1_bias), _ptr(gate_w), _ptr(gate_b),
+                                fc2_weight.data_ptr(), _ptr(fc2_bias), _ptr(r2), out.data_ptr(), work.data_ptr(),
+                                M, d, I, act, dt, _stream()))
+    return out
+
+
+def layernorm(x, weight, bias=None, eps: float = 1e-5, residual=None, residual_alpha: float = 1.0,
+              return_sum: bool = False):
+    """Drop-in for triton_layernorm (layernorm_kernels.py:191-276): optional x + alpha*residual first."""
+    _need_cuda(x, weight)
+    dt = _dtype_id(x)
+    cols = x.shape[-1]
+    x2 = x.reshape(-1, cols)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, cols)
+        if not r2.is_contiguous():
+            r2 = r2.contiguous()
+    y = torch.empty_like(x2)
+    s = torch.empty_like(x2) if (return_sum and r2 is not None) else None
+    check(lib.mio_layernorm_fwd(x2.data_ptr(), _ptr(r2), weight.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(s),
+                                x2.shape[0], cols, float(eps), float(residual_alpha), dt, _stream()))
+    y = y.view(x.shape)
+    if return_sum:
+        return y, (s.view(x.shape) if s is not None else x)
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# paged decode
+# ------------------------------------------------------------------------------------------------
+def paged_attention_forward(query, output, k_cache, v_cache, block_tables, context_lengths, block_size: int,
+                            max_seq_len: int, layer_idx: int, scale: Optional[float] = None) -> torch.Tensor:
+    """Drop-in for triton_paged_attention_forward (attention_kernels.py:1206-1311).
+    query/output [B,H,q_len,D] (output caller-preallocated, :1208,1286); caches
+    [num_blocks, L, block_size, Hkv, D]; block_tables [B,max_blocks] int32; context_lengths [B] int32."""
+    _need_cuda(query, output, k_cache, v_cache, block_tables, context_lengths)
+    if query.dim() != 4 or output.shape != query.shape:
+        raise ValueError("query/output must be [B,H,q_len,D] with equal shapes")
+    if k_cache.dim() != 5 or v_cache.shape != k_cache.shape:
+        raise ValueError("caches must be [num_blocks, num_layers, block_size, num_kv_heads, head_dim]")
+    dt = _dtype_id(query)
+    if k_cache.dtype != query.dtype or v_cache.dtype != query.dtype or output.dtype != query.dtype:
+        raise ValueError("query, output and caches must share a dtype")
+    if not (k_cache.is_contiguous() and v_cache.is_contiguous()):
+        raise ValueError("caches must be contiguous")
+    B, H, q_len, D = query.shape
+    nb, L, bs, Hkv, Dc = k_cache.shape
+    if bs != block_size or Dc != D:
+        raise ValueError("cache geometry does not match block_size/head_dim")
+    q = _rows16(query)
+    if output.stride(-1) != 1:
+        raise ValueError("output last dim must be contiguous")
+    bt = block_tables.to(torch.int32).contiguous()
+    cl = context_lengths.to(torch.int32).contiguous()
+    sc = (1.0 / math.sqrt(D)) if scale is None else float(scale)
+    nbytes = lib.mio_fa3_decode_workspace_bytes(B, H, q_len, D, int(max_seq_len))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=query.device)
+    qs = (C.c_int64 * 3)(q.stride(0), q.stride(1), q.stride(2))
+    os_ = (C.c_int64 * 3)(output.stride(0), output.stride(1), output.stride(2))
+    check(lib.mio_fa3_decode_paged(q.data_ptr(), output.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                                   bt.data_ptr(), cl.data_ptr(), qs, os_, B, H, Hkv, q_len, D, L, int(layer_idx), bs,
+                                   bt.shape[1], int(max_seq_len), sc, dt, work.data_ptr(), _stream()))
+    return output
+
+
+def reshape_and_cache(key, value, k_cache, v_cache, block_tables, context_lengths, block_size: int, layer_idx: int):
+    """Drop-in for triton_reshape_and_cache (attention_kernels.py:1314-1407): key/value [B,1,Hkv,D]."""
+    _need_cuda(key, value, k_cache, v_cache)
+    if key.dim() != 4 or key.shape[1] != 1:
+        raise ValueError("reshape_and_cache supports q_seq_len == 1 only (attention_kernels.py:1363-1365)")
+    dt = _dtype_id(key)
+    B, _, Hkv, D = key.shape
+    nb, L, bs, Hc, Dc = k_cache.shape
+    if (Hc, Dc, bs) != (Hkv, D, block_size):
+        raise ValueError("cache geometry mismatch")
+    key, value = _rows16(key), _rows16(value)
+    bt = block_tables.to(torch.int32).contiguous()
+    cl = context_lengths.to(torch.int32).contiguous()
+    ks = (C.c_int64 * 2)(key.stride(0), key.stride(2))
+    vs = (C.c_int64 * 2)(value.stride(0), value.stride(2))
+    check(lib.mio_reshape_and_cache(key.data_ptr(), value.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                                    bt.data_ptr(), cl.data_ptr(), ks, vs, B, Hkv, D, L, int(layer_idx), bs,
+                                    bt.shape[1], dt, _stream()))
+
+
+# reference-name aliases (drop-in for code written against the Triton wrappers)
+triton_flash_attention = flash_attention
+triton_ring_attention_forward = ring_attention_forward
+triton_fused_mlp = fused_mlp
+triton_layernorm = layernorm
+triton_paged_attention_forward = paged_attention_forward
+triton_reshape_and_cache = reshape_and_cache

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks at the BASELINE config-2 shapes (B8 S4096 d1024 H16, bf16), random data.
+Prints achieved TFLOP/s per kernel; used while tuning (not the driver's bench)."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ml-inference-optimizer_amd"))
+from mio import ops  # noqa: E402
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="all")
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    dev, dt = "cuda", torch.bfloat16
+    B, S, H, D, d, I = 8, 4096, 16, 64, 1024, 4096
+    M = B * S
+    torch.manual_seed(0)
+    if a.what in ("all", "attn"):
+        q, k, v = (torch.randn(B, S, H, D, device=dev, dtype=dt) for _ in range(3))
+        for causal in (True, False):
+            t = timeit(lambda: ops.fa3_fwd(q, k, v, causal=causal), a.iters)
+            fl = (2 if causal else 4) * B * S * S * d * (1 if not causal else 1)
+            if causal:
+                fl = 2 * B * S * (S + 1) * d
+            print(f"fa3_fwd causal={causal}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s")
+        q5, k5, v5 = (torch.randn(B, S, 16, 80, device=dev, dtype=dt) for _ in range(3))
+        t = timeit(lambda: ops.fa3_fwd(q5, k5, v5), a.iters)
+        print(f"fa3_fwd D=80 noncausal: {t*1e3:.3f} ms  {4*B*S*S*1280/t/1e12:.1f} TFLOP/s")
+        q8, k8, v8 = (torch.randn(B, S, 8, 128, device=dev, dtype=dt) for _ in range(3))
+        t = timeit(lambda: ops.fa3_fwd(q8, k8, v8, causal=True), a.iters)
+        print(f"fa3_fwd D=128 causal: {t*1e3:.3f} ms  {2*B*S*(S+1)*1024/t/1e12:.1f} TFLOP/s")
+    if a.what in ("all", "gemm"):
+        x = torch.randn(M, d, device=dev, dtype=dt)
+        for name, N, K, act in [("qkv", 3 * d, d, "none"), ("oproj", d, d, "none"), ("fc1+gelu", I, d, "gelu"),
+                                ("fc2", d, I, "none")]:
+            xin = torch.randn(M, K, device=dev, dtype=dt)
+            w = (torch.randn(N, K, device=dev) * 0.02).to(dt)
+            b = torch.zeros(N, device=dev, dtype=dt)
+            out = torch.empty(M, N, device=dev, dtype=dt)
+            t = timeit(lambda: ops.gemm_bias_act(xin, w, b, act, out=out), a.iters)
+            print(f"gemm {name} M={M} N={N} K={K}: {t*1e3:.3f} ms  {2*M*N*K/t/1e12:.1f} TFLOP/s")
+            tt = timeit(lambda: torch.nn.functional.linear(xin, w, b), a.iters)
+            print(f"   torch(hipBLASLt) linear: {tt*1e3:.3f} ms  {2*M*N*K/tt/1e12:.1f} TFLOP/s")
+        w1 = (torch.randn(I, d, device=dev) * 0.02).to(dt)
+        w2 = (torch.randn(d, I, device=dev) * 0.02).to(dt)
+        b1 = torch.zeros(I, device=dev, dtype=dt)
+        b2 = torch.zeros(d, device=dev, dtype=dt)
+        xs = x.view(B, S, d)
+        t = timeit(lambda: ops.fused_mlp(xs, w1, b1, w2, b2, "gelu"), a.iters)
+        print(f"fused_mlp gelu: {t*1e3:.3f} ms  {4*M*d*I/t/1e12:.1f} TFLOP/s")
+        wg = (torch.randn(I, d, device=dev) * 0.02).to(dt)
+        t = timeit(lambda: ops.fused_mlp(xs, w1, b1, w2, b2, "swiglu", wg, b1), a.iters)
+        print(f"fused_mlp swiglu: {t*1e3:.3f} ms  {6*M*d*I/t/1e12:.1f} TFLOP/s")
+    if a.what in ("all", "rows"):
+        x = torch.randn(M, d, device=dev, dtype=dt)
+        w = torch.ones(d, device=dev, dtype=dt)
+        t = timeit(lambda: ops.layernorm(x, w, w), a.iters)
+        print(f"layernorm: {t*1e6:.1f} us  {2*M*d*2/t/1e12:.2f} TB/s")
+        t = timeit(lambda: ops.layernorm(x, w, w, residual=x, return_sum=True), a.iters)
+        print(f"residual+layernorm: {t*1e6:.1f} us  {4*M*d*2/t/1e12:.2f} TB/s")
+    if a.what in ("all", "decode"):
+        bs, L, ctxlen = 16, 1, 4096
+        nblk = B * ctxlen // bs
+        kc = torch.randn(nblk, L, bs, H, D, device=dev, dtype=dt)
+        vc = torch.randn(nblk, L, bs, H, D, device=dev, dtype=dt)
+        bt = torch.randperm(nblk, device=dev).view(B, -1).to(torch.int32)
+        cl = torch.full((B,), ctxlen, device=dev, dtype=torch.int32)
+        q = torch.randn(B, H, 1, D, device=dev, dtype=dt)
+        o = torch.empty_like(q)
+        t = timeit(lambda: ops.paged_attention_forward(q, o, kc, vc, bt, cl, bs, ctxlen, 0), a.iters)
+        print(f"paged decode ctx=4096: {t*1e6:.1f} us  {2*B*ctxlen*d*2/t/1e12:.2f} TB/s")
+
+
+if __name__ == "__main__":
+    main()
