@@ -1,0 +1,59 @@
+"""Small host-side helpers shared by the nn.Module wrappers (precision casting, Linear via the HIP GEMM)."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_PRECISION = {"fp16": torch.float16, "bf16": torch.bfloat16}
+
+
+def compute_dtype(precision: str, x: torch.Tensor) -> torch.dtype:
+    """dtype the HIP kernels run in for a module configured with `precision`.
+
+    The reference casts to `config.precision` before its Triton launch
+    (flash_attention.py:176-198, fused_mlp.py:106-123).  fp16/bf16 map directly; "fp32" means
+    "keep the tensor's dtype" there, which the MFMA kernels cannot do: a 16-bit input is used as
+    is, an fp32 input raises (no silent down-cast of an fp32-configured module)."""
+    if precision in _PRECISION:
+        return _PRECISION[precision]
+    if precision == "fp32":
+        if x.dtype in (torch.float16, torch.bfloat16):
+            return x.dtype
+        raise RuntimeError("precision='fp32' with fp32 tensors is not supported by the MFMA kernels; "
+                           "configure precision='bf16' or 'fp16'")
+    if precision == "fp8":
+        raise RuntimeError("FP8 precision is not supported by the HIP path (the reference gates it to "
+                           "Hopper, flash_attention.py:89-100)")
+    raise ValueError(f"Unsupported precision mode: {precision}")
+
+
+class CastCache:
+    """Caches parameter copies in the compute dtype, keyed on (data_ptr, _version, dtype), so a module
+    whose parameters are stored in another dtype does not re-cast them on every forward."""
+
+    def __init__(self):
+        self._c: Dict[int, Tuple[Tuple, torch.Tensor]] = {}
+
+    def get(self, p: Optional[torch.Tensor], dtype: torch.dtype) -> Optional[torch.Tensor]:
+        if p is None:
+            return None
+        if p.dtype == dtype and p.is_contiguous():
+            return p.detach()
+        key = (p.data_ptr(), p._version, dtype, p.device)
+        hit = self._c.get(id(p))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        t = p.detach().to(dtype).contiguous()
+        self._c[id(p)] = (key, t)
+        return t
+
+
+def linear(x: torch.Tensor, lin: nn.Linear, cache: CastCache, dtype: torch.dtype, activation: str = "none",
+           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.linear(x, W, b) (+ activation, + residual) on the MFMA GEMM."""
+    return ops.gemm_bias_act(x, cache.get(lin.weight, dtype), cache.get(lin.bias, dtype), activation,
+                             residual=residual)

@@ -1,0 +1,329 @@
+"""Megatron-style tensor parallelism on the HIP GEMM/attention kernels + RCCL all-reduce.
+
+Mirrors reference parallelism/tensor_parallel.py: TensorParallelConfig (:16-85), ColumnParallelLinear
+(:88-204), RowParallelLinear (:207-327, the all-reduce at :302), TensorParallelMLP (:330-400),
+TensorParallelAttention (:403-614), ModelParallelConverter (:617-815).
+
+Differences that are deliberate: converted blocks COPY the original weights (the
+reference's are randomly initialised), the all-reduce runs on the tensor-parallel GROUP (the reference
+uses WORLD), and RowParallelLinear overlaps it with compute: the row-parallel GEMM is cut into row chunks
+and chunk i's all-reduce (RCCL's own stream) runs under chunk i+1's GEMM -- a TP pair on MI355X is
+bound by one ~153 GB/s xGMI link, so a 64 MiB activation costs about as much as the GEMM that made it.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Callable, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _local
+from . import communication as comm
+from .parallel_utils import divide, set_tensor_model_parallel_attributes, split_tensor_along_dim
+
+
+class TensorParallelConfig:
+    """Fields as reference :16-63; get_tp_group() returns the real group (a placeholder there, :65-75)."""
+
+    def __init__(self, world_size: int = 1, tp_size: int = 1, dp_size: Optional[int] = None, parallel_dim: int = -1,
+                 gather_output: bool = True, recompute_activation: bool = False,
+                 communication_dtype: torch.dtype = torch.float16, sequence_parallel: bool = False,
+                 gradient_accumulation_steps: int = 1, use_cpu_initialization: bool = False,
+                 overlap_chunks: int = 4):
+        self.world_size = world_size
+        self.tp_size = tp_size
+        if dp_size is None:
+            assert world_size % tp_size == 0, "World size must be divisible by tensor parallel size"
+            self.dp_size = world_size // tp_size
+        else:
+            self.dp_size = dp_size
+            assert world_size == tp_size * dp_size, "World size must equal tp_size * dp_size"
+        self.parallel_dim = parallel_dim
+        self.gather_output = gather_output
+        self.recompute_activation = recompute_activation
+        self.communication_dtype = communication_dtype
+        self.sequence_parallel = sequence_parallel
+        self.gradient_accumulation_steps = gradient_accumulation_steps
+        self.use_cpu_initialization = use_cpu_initialization
+        self.overlap_chunks = overlap_chunks  # row chunks of the GEMM -> all-reduce pipeline (1 = no overlap)
+
+    def get_tp_group(self):
+        if self.tp_size == 1 or not torch.distributed.is_initialized():
+            return None
+        return comm.setup_device_groups(self.world_size, self.tp_size)
+
+    def get_dp_group(self):
+        return None
+
+    def tp_rank(self) -> int:
+        return comm.get_rank() % self.tp_size
+
+
+class ColumnParallelLinear(nn.Module):
+    """weight [out/tp, in] (reference :88-204)."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True,
+                 config: Optional[TensorParallelConfig] = None, gather_output: Optional[bool] = None, stride: int = 1,
+                 skip_bias_add: bool = False):
+        super().__init__()
+        self.config = config or TensorParallelConfig()
+        self.in_features, self.out_features = in_features, out_features
+        self.output_size_per_partition = divide(out_features, self.config.tp_size)
+        self.weight = nn.Parameter(torch.empty(self.output_size_per_partition, in_features))
+        self.bias = nn.Parameter(torch.empty(self.output_size_per_partition)) if bias else None
+        self.reset_parameters()
+        set_tensor_model_parallel_attributes(self.weight, True, 0, stride)
+        if self.bias is not None:
+            set_tensor_model_parallel_attributes(self.bias, True, 0, stride)
+        self.gather_output = gather_output if gather_output is not None else self.config.gather_output
+        self.skip_bias_add = skip_bias_add
+        self.activation = "none"  # fused epilogue when followed by an activation (TensorParallelMLP)
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1 / math.sqrt(self.in_features)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, input: torch.Tensor):
+        fuse_bias = self.bias is not None and not self.skip_bias_add
+        out = _local.linear(input, self.weight, self.bias if fuse_bias else None, self.activation)
+        if self.gather_output and self.config.tp_size > 1:
+            out = comm.all_gather(out, dim=-1, group=self.config.get_tp_group())
+        if self.bias is not None and self.skip_bias_add:
+            return out, self.bias
+        return out
+
+    def get_master_weight(self) -> torch.Tensor:
+        if self.config.tp_size == 1:
+            return self.weight
+        return comm.all_gather(self.weight.detach(), dim=0, group=self.config.get_tp_group())
+
+
+class RowParallelLinear(nn.Module):
+    """weight [out, in/tp]; all-reduce SUM after the local GEMM, bias added once (reference :207-327)."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True,
+                 config: Optional[TensorParallelConfig] = None, input_is_parallel: bool = False, stride: int = 1,
+                 skip_bias_add: bool = False):
+        super().__init__()
+        self.config = config or TensorParallelConfig()
+        self.in_features, self.out_features = in_features, out_features
+        self.input_size_per_partition = divide(in_features, self.config.tp_size)
+        self.weight = nn.Parameter(torch.empty(out_features, self.input_size_per_partition))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        self.reset_parameters()
+        set_tensor_model_parallel_attributes(self.weight, True, 1, stride)
+        if self.bias is not None:
+            set_tensor_model_parallel_attributes(self.bias, False, 0, 1)
+        self.input_is_parallel = input_is_parallel
+        self.skip_bias_add = skip_bias_add
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1 / math.sqrt(self.in_features) / self.config.tp_size
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, input: torch.Tensor, residual: Optional[torch.Tensor] = None):
+        cfg = self.config
+        tp = cfg.tp_size
+        rank = cfg.tp_rank()
+        if not self.input_is_parallel and tp > 1:
+            input = split_tensor_along_dim(input, dim=-1, num_partitions=tp)[rank]
+        # bias (+ residual) enter the sum exactly once: fused into rank 0's GEMM epilogue (reference adds
+        # the bias after the reduce, :304-308 -- same value, one pass over the activation fewer)
+        add_here = (rank == 0)
+        bias = self.bias if (self.bias is not None and not self.skip_bias_add and add_here) else None
+        res = residual if add_here else None
+        if tp == 1 or not torch.distributed.is_initialized():
+            out = _local.linear(input, self.weight, bias, "none", res)
+        else:
+            group = cfg.get_tp_group()
+            x2 = input.reshape(-1, input.shape[-1])
+            r2 = None if res is None else res.reshape(-1, self.out_features)
+            M = x2.shape[0]
+            n = max(1, min(cfg.overlap_chunks, M // 256 if M >= 512 else 1))
+            out2 = torch.empty(M, self.out_features, dtype=input.dtype, device=input.device)
+            bounds = [(i * M) // n for i in range(n + 1)]
+            works = []
+            for i in range(n):
+                a, b = bounds[i], bounds[i + 1]
+                _local.linear(x2[a:b], self.weight, bias, "none", None if r2 is None else r2[a:b], out=out2[a:b])
+                works.append(torch.distributed.all_reduce(out2[a:b], group=group, async_op=True))
+            for w in works:
+                w.wait()  # stream-level wait on GPU; the host does not block
+            out = out2.view(*input.shape[:-1], self.out_features)
+        if self.bias is not None and self.skip_bias_add:
+            return out, self.bias
+        return out
+
+    def get_master_weight(self) -> torch.Tensor:
+        if self.config.tp_size == 1:
+            return self.weight
+        return comm.all_gather(self.weight.detach(), dim=1, group=self.config.get_tp_group())
+
+
+_ACT_NAMES = {F.gelu: "gelu_erf", F.relu: "relu", F.silu: "silu"}
+
+
+class TensorParallelMLP(nn.Module):
+    """Column-parallel fc1 (+ fused activation) -> row-parallel fc2 (+ all-reduce) (reference :330-400)."""
+
+    def __init__(self, hidden_size: int, intermediate_size: int, config: Optional[TensorParallelConfig] = None,
+                 activation: Union[Callable, str] = F.gelu):
+        super().__init__()
+        self.config = config or TensorParallelConfig()
+        self.dense_h_to_4h = ColumnParallelLinear(hidden_size, intermediate_size, bias=True, config=self.config,
+                                                  gather_output=False)
+        self.dense_4h_to_h = RowParallelLinear(intermediate_size, hidden_size, bias=True, config=self.config,
+                                               input_is_parallel=True)
+        self.activation = activation
+        if isinstance(activation, str):
+            self.dense_h_to_4h.activation = activation
+        elif activation in _ACT_NAMES:
+            self.dense_h_to_4h.activation = _ACT_NAMES[activation]
+        else:
+            raise ValueError("activation must be F.gelu / F.relu / F.silu or a kernel activation name")
+
+    def forward(self, hidden_states: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.dense_4h_to_h(self.dense_h_to_4h(hidden_states), residual=residual)
+
+
+class TensorParallelAttention(nn.Module):
+    """H/tp local heads: column-parallel q/k/v (one fused GEMM), tiled attention, row-parallel out-proj
+    (reference :403-614).  The reference's `self.key = self.value = self.query` aliasing (:480-483) is
+    not reproduced."""
+
+    def __init__(self, hidden_size: int, num_attention_heads: int, config: Optional[TensorParallelConfig] = None,
+                 attention_dropout: float = 0.0, head_dim: Optional[int] = None, is_cross_attention: bool = False,
+                 causal: bool = False):
+        super().__init__()
+        self.config = config or TensorParallelConfig()
+        tp = self.config.tp_size
+        self.hidden_size, self.num_attention_heads = hidden_size, num_attention_heads
+        self.is_cross_attention = is_cross_attention
+        self.num_heads_per_partition = divide(num_attention_heads, tp)
+        self.head_dim = head_dim if head_dim is not None else hidden_size // num_attention_heads
+        self.attention_head_size = self.head_dim
+        all_head = num_attention_heads * self.head_dim
+        self.query = ColumnParallelLinear(hidden_size, all_head, config=self.config, gather_output=False)
+        self.key = ColumnParallelLinear(hidden_size, all_head, config=self.config, gather_output=False)
+        self.value = ColumnParallelLinear(hidden_size, all_head, config=self.config, gather_output=False)
+        self.output = RowParallelLinear(all_head, hidden_size, config=self.config, input_is_parallel=True)
+        self.causal = causal
+        if attention_dropout and attention_dropout > 0:
+            self.dropout_p = attention_dropout
+        else:
+            self.dropout_p = 0.0
+
+    def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                encoder_hidden_states: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.training and self.dropout_p > 0:
+            raise NotImplementedError("attention dropout (training) is not supported by the inference kernel")
+        B, S, _ = hidden_states.shape
+        Hl, D = self.num_heads_per_partition, self.head_dim
+        kv_in = encoder_hidden_states if (self.is_cross_attention and encoder_hidden_states is not None) else hidden_states
+        q = self.query(hidden_states).view(B, S, Hl, D)
+        k = self.key(kv_in).view(B, kv_in.shape[1], Hl, D)
+        v = self.value(kv_in).view(B, kv_in.shape[1], Hl, D)
+        add = None
+        if attention_mask is not None:  # additive [B,1,Sq,Sk] / [B,1,1,Sk] like the reference (:560-566)
+            add = attention_mask
+            while add.dim() < 4:
+                add = add.unsqueeze(1)
+        ctx = _local.attention_step(q, k, v, layout="bshd", causal=self.causal, additive_mask=add)
+        return self.output(ctx.reshape(B, S, Hl * D), residual=residual)
+
+
+class ModelParallelConverter:
+    """Swap Linear / MLP / attention blocks for their tensor-parallel forms, slicing and COPYING the
+    original weights for this rank (reference :617-815 leaves new blocks randomly initialised)."""
+
+    def __init__(self, config: Optional[TensorParallelConfig] = None):
+        self.config = config or TensorParallelConfig()
+
+    def convert_model(self, model: nn.Module) -> nn.Module:
+        model_tp = copy.deepcopy(model)
+        self._convert_module(model_tp)
+        return model_tp
+
+    # -- slicing helpers
+    def _col(self, lin: nn.Linear, **kw) -> ColumnParallelLinear:
+        tp, r = self.config.tp_size, self.config.tp_rank()
+        new = ColumnParallelLinear(lin.in_features, lin.out_features, lin.bias is not None, self.config, **kw)
+        new = new.to(device=lin.weight.device, dtype=lin.weight.dtype)
+        per = lin.out_features // tp
+        with torch.no_grad():
+            new.weight.copy_(lin.weight[r * per:(r + 1) * per])
+            if lin.bias is not None:
+                new.bias.copy_(lin.bias[r * per:(r + 1) * per])
+        return new
+
+    def _row(self, lin: nn.Linear, **kw) -> RowParallelLinear:
+        tp, r = self.config.tp_size, self.config.tp_rank()
+        new = RowParallelLinear(lin.in_features, lin.out_features, lin.bias is not None, self.config, **kw)
+        new = new.to(device=lin.weight.device, dtype=lin.weight.dtype)
+        per = lin.in_features // tp
+        with torch.no_grad():
+            new.weight.copy_(lin.weight[:, r * per:(r + 1) * per])
+            if lin.bias is not None:
+                new.bias.copy_(lin.bias)
+        return new
+
+    def _convert_module(self, module: nn.Module) -> None:
+        from ..kernels.mlp.fused_mlp import FusedMLP, FusedMLPSwiGLU, FusedTransformerMLP
+        from ..kernels.attention.flash_attention import FlashAttentionLayer, FlashSelfAttention
+
+        for name, child in list(module.named_children()):
+            if isinstance(child, FusedTransformerMLP) and not isinstance(child.mlp, FusedMLPSwiGLU):
+                setattr(module, name, self._convert_fused_mlp(child.mlp))
+            elif isinstance(child, FusedMLP) and not isinstance(child, FusedMLPSwiGLU):
+                setattr(module, name, self._convert_fused_mlp(child))
+            elif isinstance(child, (FlashAttentionLayer, FlashSelfAttention)):
+                setattr(module, name, self._convert_flash_attention(child))
+            elif isinstance(child, nn.Linear):
+                # name-suffix heuristic of the reference (:659-667)
+                lname = name.lower()
+                if any(s in lname for s in ("out_proj", "o_proj", "output", "fc2", "down_proj", "dense_4h_to_h")):
+                    setattr(module, name, self._row(child, input_is_parallel=False))
+                elif any(s in lname for s in ("q_proj", "k_proj", "v_proj", "query", "key", "value", "fc1", "up_proj",
+                                              "gate_proj", "dense_h_to_4h")):
+                    setattr(module, name, self._col(child, gather_output=True))
+            else:
+                self._convert_module(child)
+
+    def _convert_fused_mlp(self, mlp) -> TensorParallelMLP:
+        act = mlp._kernel_activation()
+        d, I = mlp.fc1.in_features, mlp.fc1.out_features
+        new = TensorParallelMLP(d, I, self.config, activation=act)
+        new.dense_h_to_4h = self._col(mlp.fc1, gather_output=False)
+        new.dense_h_to_4h.activation = act
+        new.dense_4h_to_h = self._row(mlp.fc2, input_is_parallel=True)
+        return new
+
+    def _convert_flash_attention(self, att) -> TensorParallelAttention:
+        from ..kernels.attention.flash_attention import FlashSelfAttention
+
+        tp = self.config.tp_size
+        d, H = att.hidden_size, att.num_attention_heads
+        if att.num_kv_heads != H:
+            raise NotImplementedError("tensor-parallel conversion of GQA attention is not implemented")
+        new = TensorParallelAttention(d, H, self.config, causal=att.config.causal)
+        if isinstance(att, FlashSelfAttention):
+            w, b = att.qkv_proj.weight, att.qkv_proj.bias
+            parts = [(w[i * d:(i + 1) * d], b[i * d:(i + 1) * d]) for i in range(3)]
+        else:
+            parts = [(p.weight, p.bias) for p in (att.q_proj, att.k_proj, att.v_proj)]
+        for tgt, (w, b) in zip(("query", "key", "value"), parts):
+            lin = nn.Linear(d, d).to(device=w.device, dtype=w.dtype)
+            with torch.no_grad():
+                lin.weight.copy_(w)
+                lin.bias.copy_(b)
+            setattr(new, tgt, self._col(lin, gather_output=False))
+        new.output = self._row(att.o_proj, input_is_parallel=True)
+        return new

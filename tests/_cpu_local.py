@@ -1,0 +1,61 @@
+"""Checker implementations of mio.parallelism._local for the CPU (gloo) schedule tests.
+
+They reproduce the CONTRACT of the two HIP entry points (ops.gemm_bias_act, ops.fa3_fwd incl. the
+(o_acc, lse) carry) with the CPU oracle, so the distributed schedules can be exercised without a GPU.
+Test-only: the product never imports this."""
+import torch
+
+import oracle
+from oracle.mlp import gelu_tanh
+
+_ACTS = {"none": lambda x: x, "gelu": gelu_tanh, "gelu_erf": torch.nn.functional.gelu,
+         "relu": torch.relu, "silu": torch.nn.functional.silu}
+
+
+def linear(x, weight, bias=None, activation="none", residual=None, out=None):
+    y = torch.nn.functional.linear(x.double(), weight.double(), None if bias is None else bias.double())
+    y = _ACTS[activation](y)
+    if residual is not None:
+        y = y + residual.double()
+    y = y.to(x.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def attention_step(q, k, v, *, layout="bshd", causal=False, softmax_scale=None, keep_mask=None, additive_mask=None,
+                   return_lse=False, out=None, o_acc=None, lse=None, carry_in=False, write_out=True, q_offset=0,
+                   k_offset=0):
+    if layout == "bhsd":
+        qs, ks, vs = (t.permute(0, 2, 1, 3) for t in (q, k, v))
+    else:
+        qs, ks, vs = q, k, v
+    o_new, lse_new = oracle.attention_with_lse(qs, ks, vs, mask=keep_mask, causal=causal, softmax_scale=softmax_scale,
+                                               additive_mask=additive_mask, q_offset=q_offset, k_offset=k_offset)
+    if carry_in:
+        o_new, lse_new = oracle.merge_attention_states(o_acc, lse, o_new, lse_new)
+    if o_acc is not None:
+        o_acc.copy_(o_new.float())
+        lse.copy_(lse_new.float())
+    res = None
+    if write_out:
+        res = o_new.to(q.dtype)
+        if layout == "bhsd":
+            res = res.permute(0, 2, 1, 3)
+        if out is not None:
+            out.copy_(res)
+            res = out
+    if return_lse:
+        return res, lse_new.float()
+    return res
+
+
+def install(monkeypatch=None):
+    from mio.parallelism import _local
+    if monkeypatch is not None:
+        monkeypatch.setattr(_local, "linear", linear)
+        monkeypatch.setattr(_local, "attention_step", attention_step)
+    else:
+        _local.linear = linear
+        _local.attention_step = attention_step
