@@ -1,0 +1,64 @@
+"""Synthetic GPT-2-shaped block stack used for measurement: random weights,
+hidden states in / hidden states out.  Per layer:
+    LN -> FlashSelfAttention (fused qkv GEMM, tiled attention, out-proj GEMM + residual)
+       -> LN -> FusedTransformerMLP (fc1 GEMM + act, fc2 GEMM + residual)
+All compute runs in the HIP kernels; residual adds are fused into the GEMM epilogues."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .kernels.attention.flash_attention import FlashAttentionConfig, FlashSelfAttention, FlashAttentionLayer
+from .kernels.mlp.fused_mlp import FusedMLPConfig, FusedTransformerMLP
+
+
+class FusedLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm whose forward is the HIP row kernel (reference layernorm_kernels.py:191-276)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise ValueError("HIP kernels require input tensors to be on a CUDA (ROCm) device.")
+        return ops.layernorm(x, self.weight, self.bias, self.eps)
+
+
+class Block(nn.Module):
+    def __init__(self, d: int, H: int, I: int, causal: bool, precision: str, activation: str = "gelu",
+                 cross_attention: bool = False):
+        super().__init__()
+        acfg = FlashAttentionConfig(causal=causal, precision=precision)
+        self.ln_1 = FusedLayerNorm(d)
+        self.attn = FlashSelfAttention(d, H, acfg)
+        self.ln_2 = FusedLayerNorm(d)
+        self.mlp = FusedTransformerMLP(d, I, activation, FusedMLPConfig(precision=precision))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.attn(self.ln_1(x), residual=x)
+        return self.mlp(self.ln_2(x), residual=x)
+
+
+class GPT2ShapedStack(nn.Module):
+    """d=1024, H=16, L=24 is the GPT-2-medium shape of BASELINE config 2."""
+
+    def __init__(self, hidden_size: int = 1024, num_heads: int = 16, num_layers: int = 24,
+                 intermediate_size: Optional[int] = None, causal: bool = True, precision: str = "bf16",
+                 activation: str = "gelu", seed: int = 0):
+        super().__init__()
+        I = intermediate_size or 4 * hidden_size
+        self.h = nn.ModuleList([Block(hidden_size, num_heads, I, causal, precision, activation)
+                                for _ in range(num_layers)])
+        self.ln_f = FusedLayerNorm(hidden_size)
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():  # N(0, 0.02) weights, zero biases (flash_attention.py:534-542)
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=g) * 0.02)
+                    m.bias.zero_()
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        for blk in self.h:
+            x = blk(x)
+        return self.ln_f(x)

@@ -1,0 +1,142 @@
+"""GPU parity of the operator surface (modules / converters / Optimizer facade / synthetic stack)."""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().mean() / b.abs().mean()).item()
+
+
+@pytest.mark.parametrize("dtype,prec", [(torch.bfloat16, "bf16"), (torch.float16, "fp16")])
+@pytest.mark.parametrize("cls", ["layer", "self"])
+def test_attention_layers(dtype, prec, cls):
+    from mio.kernels.attention import FlashAttentionConfig, FlashAttentionLayer, FlashSelfAttention
+    torch.manual_seed(0)
+    d, H, Hkv, B, S = 128, 8, 4, 2, 150
+    cfg = FlashAttentionConfig(causal=True, precision=prec)
+    m = (FlashAttentionLayer if cls == "layer" else FlashSelfAttention)(d, H, cfg, num_kv_heads=Hkv)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn_like(p) * 0.1)
+    m = m.to(DEV, dtype).eval()
+    x = torch.randn(B, S, d, device=DEV, dtype=dtype)
+    y = m(x)
+    D = d // H
+    xf = x.cpu().double()
+    sd = {k: v.cpu().double() for k, v in m.state_dict().items()}
+    if cls == "layer":
+        q = F.linear(xf, sd["q_proj.weight"], sd["q_proj.bias"])
+        k = F.linear(xf, sd["k_proj.weight"], sd["k_proj.bias"])
+        v = F.linear(xf, sd["v_proj.weight"], sd["v_proj.bias"])
+    else:
+        qkv = F.linear(xf, sd["qkv_proj.weight"], sd["qkv_proj.bias"])
+        q, k, v = qkv[..., :d], qkv[..., d:d + Hkv * D], qkv[..., d + Hkv * D:]
+    ctx = oracle.standard_attention(q.view(B, S, H, D), k.reshape(B, S, Hkv, D), v.reshape(B, S, Hkv, D), causal=True)
+    ref = F.linear(ctx.reshape(B, S, d), sd["o_proj.weight"], sd["o_proj.bias"])
+    assert _rel(y, ref) < (2e-2 if dtype == torch.bfloat16 else 3e-3)
+    # fp32 activations with 16-bit precision configured: cast in, cast back (flash_attention.py:176-225)
+    y32 = m.float()(x.float())
+    assert y32.dtype == torch.float32 and _rel(y32, ref) < 2e-2
+
+
+def test_flash_attention3_module_and_mask():
+    from mio.kernels.attention import FlashAttention3, FlashAttentionConfig, ModelConverter
+    torch.manual_seed(1)
+    q, k, v = (torch.randn(2, 100, 4, 64, device=DEV) for _ in range(3))  # fp32 in, fp16 compute (default precision)
+    fa = FlashAttention3(FlashAttentionConfig(causal=False))
+    mask = torch.ones(2, 100, device=DEV)
+    mask[1, 60:] = 0
+    o = fa(q, k, v, ModelConverter.convert_mask(mask))
+    assert o.dtype == torch.float32
+    ref = oracle.standard_attention(q.cpu().half(), k.cpu().half(), v.cpu().half(), mask=mask.cpu())
+    assert (o.cpu().double() - ref).abs().max() < 4e-3
+    with pytest.raises(NotImplementedError):
+        FlashAttention3(FlashAttentionConfig(return_softmax=True))(q, k, v)
+
+
+def test_paged_path_through_module():
+    from mio.kernels.attention import FlashAttentionConfig, FlashSelfAttention
+    torch.manual_seed(2)
+    d, H, B, bs, L, nblk = 128, 4, 2, 16, 2, 16
+    D = d // H
+    dt = torch.float16
+    m = FlashSelfAttention(d, H, FlashAttentionConfig(precision="fp16")).to(DEV, dt).eval()
+    kc = torch.randn(nblk, L, bs, H, D, device=DEV, dtype=dt)
+    vc = torch.randn(nblk, L, bs, H, D, device=DEV, dtype=dt)
+    bt = torch.stack([torch.randperm(nblk)[:6] for _ in range(B)]).to(torch.int32).to(DEV)
+    cl = torch.tensor([70, 33], dtype=torch.int32, device=DEV)
+    x = torch.randn(B, 1, d, device=DEV, dtype=dt)
+    y = m(x, physical_kv_cache_k=kc, physical_kv_cache_v=vc, block_tables=bt, context_lengths=cl,
+          kv_cache_block_size=bs, max_seq_len=96, layer_idx=1)
+    sd = {k_: v_.cpu().double() for k_, v_ in m.state_dict().items()}
+    q = F.linear(x.cpu().double(), sd["qkv_proj.weight"][:d], sd["qkv_proj.bias"][:d]).view(B, 1, H, D).permute(0, 2, 1, 3)
+    ctx = oracle.paged_attention_forward(q, kc.cpu(), vc.cpu(), bt.cpu(), cl.cpu(), bs, 1)
+    ref = F.linear(ctx.permute(0, 2, 1, 3).reshape(B, 1, d), sd["o_proj.weight"], sd["o_proj.bias"])
+    assert _rel(y, ref) < 5e-3
+    with pytest.raises(ValueError):
+        m(x, block_tables=bt)
+
+
+def test_optimizer_facade_end_to_end():
+    """Optimizer(model).optimize(...) on the plain GPT-2-shaped stack == the plain model (the reference's
+    stated criterion, test_parallelism.py:306-322, at bf16 tolerance instead of 0.1)."""
+    from ml_inference_optimizer import Optimizer
+    from oracle.baseline_runner import PlainGPT2Stack
+    torch.manual_seed(0)
+    plain = PlainGPT2Stack(128, 4, 2, seed=5).eval()
+    x = torch.randn(2, 96, 128)
+    with torch.no_grad():
+        ref = plain(x)
+    model = copy.deepcopy(plain).to(DEV, torch.bfloat16)
+    opt = Optimizer(model).optimize(use_flash_attention=True, use_fused_mlp=True, tensor_parallel_size=1,
+                                    use_custom_layernorm=True, causal=True)
+    with torch.no_grad():
+        y = opt(x.to(DEV, torch.bfloat16))
+    assert _rel(y, ref) < 2e-2 and (y.float().cpu() - ref).abs().max() < 0.15
+
+
+def test_synthetic_stack_matches_plain_stack():
+    """The benchmark model (mio.synthetic) == the oracle's plain fp32 stack with the same weights."""
+    from mio.synthetic import GPT2ShapedStack
+    from oracle.baseline_runner import PlainGPT2Stack
+    d, H, L, B, S = 128, 4, 3, 2, 200
+    plain = PlainGPT2Stack(d, H, L, seed=7).eval()
+    fast = GPT2ShapedStack(d, H, L, causal=True, precision="bf16")
+    with torch.no_grad():
+        for i in range(L):
+            a, b = plain.h[i], fast.h[i]
+            b.attn.qkv_proj.weight.copy_(torch.cat([a.attn.q_proj.weight, a.attn.k_proj.weight, a.attn.v_proj.weight]))
+            b.attn.qkv_proj.bias.copy_(torch.cat([a.attn.q_proj.bias, a.attn.k_proj.bias, a.attn.v_proj.bias]))
+            b.attn.o_proj.load_state_dict(a.attn.o_proj.state_dict())
+            b.mlp.mlp.fc1.load_state_dict(a.mlp.linear1.state_dict())
+            b.mlp.mlp.fc2.load_state_dict(a.mlp.linear2.state_dict())
+            b.ln_1.load_state_dict(a.ln_1.state_dict())
+            b.ln_2.load_state_dict(a.ln_2.state_dict())
+        fast.ln_f.load_state_dict(plain.ln_f.state_dict())
+    x = torch.randn(B, S, d)
+    with torch.no_grad():
+        ref = plain(x)
+        y = fast.to(DEV, torch.bfloat16)(x.to(DEV, torch.bfloat16))
+    assert _rel(y, ref) < 2e-2
+
+
+def test_mlp_converter_module_on_gpu():
+    from mio.kernels.mlp import FusedTransformerMLP
+    torch.manual_seed(3)
+    for act, oact in (("gelu", "gelu"), ("swiglu", "swiglu"), ("relu", "relu"), ("silu", "silu")):
+        m = FusedTransformerMLP(128, 256, act).to(DEV, torch.float16).eval()
+        x = torch.randn(2, 50, 128, device=DEV, dtype=torch.float16)
+        y = m(x)
+        sd = {k: v.cpu() for k, v in m.state_dict().items()}
+        ref = oracle.fused_mlp(x.cpu(), sd["mlp.fc1.weight"], sd["mlp.fc1.bias"], sd["mlp.fc2.weight"], sd["mlp.fc2.bias"],
+                               oact, sd.get("mlp.fc1_gate.weight"), sd.get("mlp.fc1_gate.bias"))
+        assert _rel(y, ref) < 3e-3

@@ -1,0 +1,177 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol of include/mio_hip.h, the operator
+surface mirrors the reference's names/errors, converters copy weights, host-side helpers."""
+import os
+import re
+
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_match_header():
+    from mio import _lib
+    hdr = open(os.path.join(ROOT, "include", "mio_hip.h")).read()
+    declared = set(re.findall(r"\b(mio_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(_lib.lib, name), name
+    assert _lib.lib.mio_version() == 100
+    assert _lib.lib.mio_last_error() is not None  # callable without a GPU
+
+
+def test_cabi_argument_errors_without_gpu():
+    """Validation happens before any launch, so bad arguments are reportable without a device."""
+    import ctypes as C
+    from mio import _lib
+    p = _lib.FaParams()
+    assert _lib.lib.mio_fa3_fwd(C.byref(p), None) != 0
+    assert b"non-null" in _lib.lib.mio_last_error()
+    assert _lib.lib.mio_gemm_bias_act(None, None, None, None, None, None, None, 1, 8, 8, 8, 8, 8, 8, 0, 0, None) != 0
+    with pytest.raises(RuntimeError):
+        _lib.check(-1)
+
+
+def test_no_cpu_fallback():
+    from mio import ops
+    from mio.kernels.mlp import FusedTransformerMLP
+    from mio.kernels.attention import FlashAttention3, FlashSelfAttention
+    x = torch.randn(1, 4, 64)
+    with pytest.raises(ValueError):
+        FusedTransformerMLP(64, 128)(x)
+    with pytest.raises(ValueError):
+        FlashSelfAttention(64, 4)(x)
+    q = torch.randn(1, 4, 2, 32)
+    with pytest.raises(ValueError):
+        FlashAttention3()(q, q, q)
+    with pytest.raises(ValueError):
+        ops.flash_attention(q, q, q)
+    with pytest.raises(ValueError):
+        FlashAttention3()(q[0], q, q)  # rank check first, like flash_attention.py:167
+
+
+def test_configs_mirror_reference():
+    from mio.kernels.attention import FlashAttentionConfig
+    from mio.kernels.mlp import FusedMLPConfig
+    from mio.parallelism import SequenceParallelConfig, TensorParallelConfig
+    c = FlashAttentionConfig()
+    assert (c.block_size, c.causal, c.softmax_scale, c.dropout_p, c.precision) == (128, False, None, 0.0, "fp16")
+    with pytest.raises(ValueError):
+        FlashAttentionConfig(precision="int8")
+    with pytest.raises(RuntimeError):
+        FlashAttentionConfig(precision="fp8")
+    m = FusedMLPConfig()
+    assert (m.activation_fn, m.dropout_prob, m.precision) == ("gelu", 0.0, "fp16")
+    with pytest.raises(ValueError):
+        SequenceParallelConfig(world_size=4, sp_size=3)
+    with pytest.raises(ValueError):
+        SequenceParallelConfig(attention_handling="striped")
+    t = TensorParallelConfig(world_size=8, tp_size=2)
+    assert t.dp_size == 4
+    from mio.kernels.attention import FlashAttentionLayer
+    with pytest.raises(ValueError):
+        FlashAttentionLayer(100, 3)
+
+
+def test_module_parameter_names():
+    from mio.kernels.attention import FlashAttentionLayer, FlashSelfAttention
+    from mio.kernels.mlp import FusedTransformerMLP
+    assert set(dict(FlashAttentionLayer(64, 4, num_kv_heads=2).named_parameters())) == {
+        f"{p}.{w}" for p in ("q_proj", "k_proj", "v_proj", "o_proj") for w in ("weight", "bias")}
+    fs = FlashSelfAttention(64, 4, num_kv_heads=2)
+    assert fs.qkv_proj.weight.shape == (64 + 2 * 2 * 16, 64)
+    sw = FusedTransformerMLP(64, 128, "swiglu")
+    assert {"mlp.fc1.weight", "mlp.fc1_gate.weight", "mlp.fc2.weight"} <= set(dict(sw.named_parameters()))
+    assert type(FusedTransformerMLP(64, 128, "gelu").mlp).__name__ == "FusedMLPGeluTanh"
+    assert type(FusedTransformerMLP(64, 128, "relu").mlp).__name__ == "FusedMLPReLU"
+    assert type(FusedTransformerMLP(64, 128, "silu").mlp).__name__ == "FusedMLP"
+
+
+def test_converters_copy_weights():
+    from oracle.baseline_runner import PlainGPT2Stack
+    from ml_inference_optimizer import Optimizer
+    from mio.kernels.attention import FlashAttentionLayer
+    from mio.kernels.mlp import FusedTransformerMLP
+    model = PlainGPT2Stack(64, 4, 2, seed=3)
+    ref = {k: v.clone() for k, v in model.state_dict().items()}
+    opt = Optimizer(model)
+    prof = opt.profile()
+    assert prof["attention_modules"] == 2 and prof["mlp_modules"] == 2
+    out = opt.optimize(use_flash_attention=True, use_fused_mlp=True, tensor_parallel_size=1, causal=True)
+    blk = out.h[0]
+    assert isinstance(blk.attn, FlashAttentionLayer) and isinstance(blk.mlp, FusedTransformerMLP)
+    assert blk.attn.config.causal is True
+    assert torch.equal(blk.attn.q_proj.weight, ref["h.0.attn.q_proj.weight"])
+    assert torch.equal(blk.attn.o_proj.bias, ref["h.0.attn.o_proj.bias"])
+    assert torch.equal(blk.mlp.mlp.fc1.weight, ref["h.0.mlp.linear1.weight"])
+    assert torch.equal(blk.mlp.mlp.fc2.weight, ref["h.0.mlp.linear2.weight"])
+    assert type(blk.mlp.mlp).__name__ == "FusedMLPGeluTanh"
+
+
+def test_converter_llama_and_gpt2_layouts():
+    from mio.kernels.mlp import MLPConverter
+    from mio.kernels.attention import ModelConverter, FlashSelfAttention
+
+    class LlamaMLP(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.gate_proj = nn.Linear(32, 64, bias=False)
+            self.up_proj = nn.Linear(32, 64, bias=False)
+            self.down_proj = nn.Linear(64, 32, bias=False)
+
+    class Conv1D(nn.Module):  # HF GPT-2 layout: weight [in, out]
+        def __init__(self, nf, nx):
+            super().__init__()
+            self.weight = nn.Parameter(torch.randn(nx, nf))
+            self.bias = nn.Parameter(torch.randn(nf))
+
+    class GPT2MLP(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c_fc, self.c_proj, self.act = Conv1D(64, 32), Conv1D(32, 64), nn.GELU()
+
+    class GPT2Attention(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c_attn, self.c_proj = Conv1D(96, 32), Conv1D(32, 32)
+            self.num_heads, self.embed_dim = 4, 32
+
+    class Holder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.attn = LlamaMLP(), GPT2MLP(), GPT2Attention()
+
+    h = Holder()
+    src = {k: v.clone() for k, v in h.state_dict().items()}
+    MLPConverter().convert_model(h)
+    assert torch.equal(h.a.mlp.fc1_gate.weight, src["a.gate_proj.weight"])
+    assert torch.equal(h.a.mlp.fc1.weight, src["a.up_proj.weight"])
+    assert torch.equal(h.a.mlp.fc2.weight, src["a.down_proj.weight"])
+    assert h.a.mlp.fc2.bias.abs().max() == 0
+    assert torch.equal(h.b.mlp.fc1.weight, src["b.c_fc.weight"].t())
+    assert torch.equal(h.b.mlp.fc2.bias, src["b.c_proj.bias"])
+    ModelConverter().convert_model(h)
+    assert isinstance(h.attn, FlashSelfAttention) and h.attn.num_attention_heads == 4
+    assert torch.equal(h.attn.qkv_proj.weight, src["attn.c_attn.weight"].t())
+    assert torch.equal(h.attn.o_proj.weight, src["attn.c_proj.weight"].t())
+
+
+def test_sequence_helpers():
+    from mio.parallelism import partition_sequence, gather_sequence, zigzag_shard, zigzag_unshard
+    x = torch.arange(2 * 16 * 3).view(2, 16, 3)
+    parts = partition_sequence(x, 4)
+    assert len(parts) == 4 and torch.equal(gather_sequence(parts), x)
+    with pytest.raises(ValueError):
+        partition_sequence(x, 5)
+    shards = [zigzag_shard(x, r, 4) for r in range(4)]
+    assert torch.equal(shards[0][:, :2], x[:, 0:2]) and torch.equal(shards[0][:, 2:], x[:, 14:16])
+    assert torch.equal(zigzag_unshard(shards, 4), x)
+
+
+def test_comm_wrappers_single_process():
+    from mio.parallelism import all_reduce, all_gather, reduce_scatter, ring_exchange, get_rank, get_world_size
+    t = torch.ones(3)
+    assert get_rank() == 0 and get_world_size() == 1
+    assert all_reduce(t) is t and all_gather(t) is t and reduce_scatter(t) is t
+    assert ring_exchange(t, None)[0] is t
