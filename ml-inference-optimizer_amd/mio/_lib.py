@@ -8,6 +8,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch must be loaded first: it ships its own HIP runtime (torch/lib/libamdhip64.so, SONAME
+# libamdhip64.so.7).  With it already mapped, libmio_hip.so's NEEDED libamdhip64.so.7 binds to that same
+# runtime, so torch's streams/events/allocations and our launches live in ONE HIP runtime.  (Loaded the other
+# way round, /opt/rocm's copy would be pulled in first and the process would hold two runtimes.)
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmio_hip.so")
 
