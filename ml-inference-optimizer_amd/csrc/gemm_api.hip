@@ -30,6 +30,7 @@ extern "C" int mio_gemm_bias_act(const void* x, const void* w, const void* bias,
   p.x = x; p.w = w; p.wg = w_gate; p.bias = bias; p.bias_g = bias_gate; p.res = residual; p.y = y;
   p.M = M; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldr = ldr; p.N = N; p.K = K;
   p.tiles_m = p.tiles_n = 0;
+  p.dbg = nullptr;
   return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
 }
 

@@ -1,5 +1,10 @@
 // One translation unit per dtype: compiled with -DGEMM_TYPE_ID={0,1}.
-#include "gemm_kernel.h"
+#include <cstdio>
+#include <cstdlib>
+
+#include "gemm4w16_kernel.h"
+#include "gemm4w_kernel.h"
+#include "gemm8p_kernel.h"
 
 #if GEMM_TYPE_ID == 0
 using GT = __bf16;
@@ -26,6 +31,102 @@ static int launch_cfg(GemmDev p, hipStream_t stream) {
   return 0;
 }
 
+static int gemm_var() {  // MIO_GEMM_VAR=<bits>: timing-only ablations of the ACT_NONE 8-phase kernel (tuning aid)
+  static const int v = [] {
+    const char* e = std::getenv("MIO_GEMM_VAR");
+    return e ? std::atoi(e) : 0;
+  }();
+  return v;
+}
+
+template <int ACT, int VAR = 0>
+static int launch_8p(GemmDev p, hipStream_t stream) {
+  if constexpr (ACT == MIO_ACT_NONE && VAR == 0) {
+    switch (gemm_var()) {
+      case 1: return launch_8p<ACT, 1>(p, stream);
+      case 2: return launch_8p<ACT, 2>(p, stream);
+      case 4: return launch_8p<ACT, 4>(p, stream);
+      case 8: return launch_8p<ACT, 8>(p, stream);
+      case 12: return launch_8p<ACT, 12>(p, stream);
+      default: break;
+    }
+  }
+  p.tiles_m = (int)((p.M + 255) / 256);
+  p.tiles_n = (p.N + 255) / 256;
+  auto kern = gemm8p_kernel<GT, ACT, VAR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G8_SMEM);
+    if (e != hipSuccess) return mio_fail(std::string("gemm8p: hipFuncSetAttribute: ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), G8_SMEM, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("gemm8p launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+static int gemm_var();
+template <int ACT, int VAR = 0>
+static int launch_4w(GemmDev p, hipStream_t stream) {
+  if constexpr (ACT == MIO_ACT_NONE && VAR == 0) {
+    switch (gemm_var()) {
+      case 4: return launch_4w<ACT, 4>(p, stream);
+      case 8: return launch_4w<ACT, 8>(p, stream);
+      case 12: return launch_4w<ACT, 12>(p, stream);
+      default: break;
+    }
+  }
+  p.tiles_m = (int)((p.M + 255) / 256);
+  p.tiles_n = (p.N + 255) / 256;
+  auto kern = gemm4w_kernel<GT, ACT, VAR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G4_SMEM);
+    if (e != hipSuccess) return mio_fail(std::string("gemm4w: hipFuncSetAttribute: ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), G4_SMEM, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("gemm4w launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+static int gemm_var();
+template <int ACT, int VAR = 0>
+static int launch_4w16(GemmDev p, hipStream_t stream) {
+  if constexpr (ACT == MIO_ACT_NONE && VAR == 0) {
+    if (gemm_var() == 16) return launch_4w16<ACT, 16>(p, stream);
+    if (p.dbg != nullptr) return launch_4w16<ACT, 32>(p, stream);
+  }
+  p.tiles_m = (int)((p.M + 255) / 256);
+  p.tiles_n = (p.N + 255) / 256;
+  auto kern = gemm4w16_kernel<GT, ACT, VAR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G6_SMEM);
+    if (e != hipSuccess) return mio_fail(std::string("gemm4w16: hipFuncSetAttribute: ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), G6_SMEM, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("gemm4w16 launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+// MIO_GEMM_IMPL=v1|8p selects an older pipeline for A/B comparisons (read once); default = 4-wave kernel.
+static int gemm_impl() {
+  static const int v = [] {
+    const char* e = std::getenv("MIO_GEMM_IMPL");
+    if (e == nullptr) return 0;
+    if (std::string(e) == "v1") return 1;
+    if (std::string(e) == "8p") return 2;
+    if (std::string(e) == "4w") return 3;
+    return 0;
+  }();
+  return v;
+}
+
 template <int ACT>
 static int launch_act(const GemmDev& p, hipStream_t stream) {
   // Big tiles when they still fill the chip (>= 256 workgroups), else 128x128.
@@ -36,13 +137,23 @@ static int launch_act(const GemmDev& p, hipStream_t stream) {
     return launch_cfg<128, 64, 2, 2, ACT>(p, stream);
   } else {
     const int64_t big = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    if (big >= 256) return launch_cfg<256, 256, 2, 4, ACT>(p, stream);
+    if (big >= 256) {
+      if (gemm_impl() == 1) return launch_cfg<256, 256, 2, 4, ACT>(p, stream);
+      if (gemm_impl() == 2) return launch_8p<ACT>(p, stream);
+      if (gemm_impl() == 3) return launch_4w<ACT>(p, stream);
+      return launch_4w16<ACT>(p, stream);
+    }
     return launch_cfg<128, 128, 2, 2, ACT>(p, stream);
   }
 }
 
 template <>
 int gemm_launch<GT>(GemmDev p, int act, hipStream_t stream) {
+  if (const char* e = std::getenv("MIO_GEMM_DBG_PTR")) {
+    p.dbg = (unsigned long long*)std::strtoull(e, nullptr, 0);
+    static int once = 0;
+    if (!once++) fprintf(stderr, "[mio] gemm stamps -> %p (act %d)\n", (void*)p.dbg, act);
+  }
   switch (act) {
     case MIO_ACT_NONE: return launch_act<MIO_ACT_NONE>(p, stream);
     case MIO_ACT_GELU_TANH: return launch_act<MIO_ACT_GELU_TANH>(p, stream);

@@ -29,6 +29,7 @@ struct GemmDev {
   int64_t M, ldx, ldw, ldy, ldr;
   int N, K;
   int tiles_m, tiles_n;
+  unsigned long long* dbg;  // diagnostic builds only (in-kernel stamps); nullptr otherwise
 };
 
 constexpr int GEMM_BK = 64;
@@ -66,6 +67,87 @@ __device__ __forceinline__ void gemm_tile_coords(int id, int tiles_m, int tiles_
   const int within = pid - g * per_group;
   tm = first_m + within % gsz;
   tn = within / gsz;
+}
+
+// ---- shared epilogue --------------------------------------------------------------------------------
+// Accumulator layout (weight tile = A operand, activation tile = B operand): lane (r, h) holds output row
+// mbase + mt*32 + r and, per register group g, the 4 consecutive columns nbase + nt*32 + 8g + 4h + (0..3).
+// All bias / residual loads of a row block are issued before the first use (clamped addresses instead of
+// branches), so the epilogue pays one memory round trip per row block instead of one per 8-byte store.
+template <typename T, int ACT, int NT, int MT>
+__device__ __forceinline__ void gemm_epilogue(const GemmDev& p, f32x16_t (&acc)[NT][MT],
+                                              f32x16_t (&accg)[(ACT == MIO_ACT_SWIGLU) ? NT : 1][(ACT == MIO_ACT_SWIGLU) ? MT : 1],
+                                              int64_t mbase, int nbase, int r, int h) {
+  using X4 = typename DT<T>::x4;
+  constexpr bool GATE = (ACT == MIO_ACT_SWIGLU);
+  int ncol[NT][4];
+  bool nok[NT][4];
+  X4 bv[NT][4], bgv[GATE ? NT : 1][GATE ? 4 : 1];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = nbase + nt * 32 + 8 * g + 4 * h;
+      nok[nt][g] = n < p.N;
+      ncol[nt][g] = nok[nt][g] ? n : (p.N - 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[nt][g][e] = (T)0.f;
+    }
+  if (p.bias) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bv[nt][g] = *(const X4*)((const T*)p.bias + ncol[nt][g]);
+  }
+  if constexpr (GATE) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bgv[nt][g][e] = (T)0.f;
+        if (p.bias_g) bgv[nt][g] = *(const X4*)((const T*)p.bias_g + ncol[nt][g]);
+      }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int64_t m = mbase + mt * 32 + r;
+    const bool mok = m < p.M;
+    const int64_t mc = mok ? m : (p.M - 1);
+    T* yrow = (T*)p.y + mc * p.ldy;
+    X4 rv[NT][4];
+    if (p.res) {
+      const T* rrow = (const T*)p.res + mc * p.ldr;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rv[nt][g] = *(const X4*)(rrow + ncol[nt][g]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * g + e] + (float)bv[nt][g][e];
+        if constexpr (GATE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = gemm_act<MIO_ACT_SILU>(accg[nt][mt][4 * g + e] + (float)bgv[nt][g][e]) * v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gemm_act<ACT>(v[e]);
+        }
+        if (p.res) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[nt][g][e];
+        }
+        if (mok && nok[nt][g]) {
+          u32x2_t o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+          *(u32x2_t*)(yrow + ncol[nt][g]) = o;
+        }
+      }
+  }
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int ACT>
@@ -188,51 +270,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bias_act_kernel(const GemmDe
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds row m = .. + r, columns n = nt*32 + 8g + 4h + (0..3) per register group g
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int64_t m = m0 + wm * TM + mt * 32 + r;
-    if (m >= p.M) continue;
-    T* yrow = (T*)p.y + m * p.ldy;
-    const T* rrow = p.res ? ((const T*)p.res + m * p.ldr) : nullptr;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * TN + nt * 32 + 8 * g + 4 * h;
-        if (n >= p.N) continue;
-        float v[4], gt[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[nt][mt][4 * g + e];
-          if (GATE) gt[e] = accg[nt][mt][4 * g + e];
-        }
-        if (p.bias) {
-          const typename DT<T>::x4 bv = *(const typename DT<T>::x4*)((const T*)p.bias + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-        }
-        if (GATE) {
-          if (p.bias_g) {
-            const typename DT<T>::x4 bv = *(const typename DT<T>::x4*)((const T*)p.bias_g + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gt[e] += (float)bv[e];
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gemm_act<MIO_ACT_SILU>(gt[e]) * v[e];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gemm_act<ACT>(v[e]);
-        }
-        if (rrow) {
-          const typename DT<T>::x4 rv = *(const typename DT<T>::x4*)(rrow + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-        }
-        u32x2_t o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-        *(u32x2_t*)(yrow + n) = o;
-      }
-  }
+  gemm_epilogue<T, ACT, NT, MT>(p, acc, accg, m0 + wm * TM, n0 + wn * TN, r, h);
 }
 
 // Host launcher for one dtype; defined per translation unit (gemm_inst.hip).

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""A/B timing of GEMM shapes (C2 layer) for the current MIO_GEMM_VAR / MIO_GEMM_IMPL environment."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ml-inference-optimizer_amd"))
+from mio import ops
+from tools.kbench import timeit
+M, d, I, dt, dev = 32768, 1024, 4096, torch.bfloat16, "cuda"
+torch.manual_seed(0)
+res = []
+for name, N, K in (("qkv", 3 * d, d), ("oproj", d, d), ("fc2", d, I)):
+    x = torch.randn(M, K, device=dev, dtype=dt)
+    w = (torch.randn(N, K, device=dev) * 0.02).to(dt)
+    out = torch.empty(M, N, device=dev, dtype=dt)
+    t = timeit(lambda: ops.gemm_bias_act(x, w, None, out=out), 20)
+    res.append(f"{name} {t*1e3:.3f}ms {2*M*N*K/t/1e12:.0f}TF")
+print(os.environ.get("MIO_GEMM_VAR", "0"), os.environ.get("MIO_GEMM_IMPL", "8p"), " | ".join(res))
