@@ -19,6 +19,8 @@
 //   * LDS images: K rows padded by 16 B (conflict-free ds_read_b128 for any D), V as
 //     [key/8][d/32][8][32] sub-tiles (each half-wave's transposed read covers one 256-B bank row).
 #pragma once
+#include <type_traits>
+
 #include "mio_common.h"
 
 struct FaDev {
@@ -44,7 +46,8 @@ constexpr int FA_BM = 128;
 constexpr int FA_BN = 64;
 constexpr float FA_LOG2E = 1.4426950408889634f;
 constexpr float FA_LN2 = 0.6931471805599453f;
-constexpr float FA_NEG_FILL_LOG2 = -1.0e9f * FA_LOG2E;  // the reference's -1e9 fill, in the exp2 domain
+constexpr float FA_NEG_FILL_LOG2 = -1.0e9f * FA_LOG2E;
+constexpr float FA_RESCALE_THR = 6.0f;  // exp2 domain: P <= 64 between rescales
 
 template <int D>
 struct FaSmem {
@@ -194,127 +197,142 @@ __global__ __launch_bounds__(256) void fa3_fwd_kernel(const FaDev p) {
   const int q_pos = qrow + p.q_offset;
   const float c2 = p.scale_log2e;
 
+  // One KV tile for this wave.  EDGE = the tile needs per-element masking (causal diagonal, keys past Sk, or any
+  // user mask); interior tiles (the vast majority) compile to the bare online-softmax update with no compares.
+  auto process_tile = [&](int t, auto EDGE_) {
+    constexpr bool EDGE = decltype(EDGE_)::value;
+    const int cur = t & 1;
+    const int kv0 = t * FA_BN;
+    const char* kb = smem + cur * SM::STAGE;
+    const char* vb = kb + SM::K_BYTES;
+
+    // ---- S^T = K . Q^T   (two 32-key tiles)
+    f32x16_t s0, s1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s0[i] = 0.f;
+      s1[i] = 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const X8 a0 = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + k_rd + 32 * ks));
+      const X8 a1 = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + k_rd + 32 * SM::KROW + 32 * ks));
+      s0 = DT<T>::mfma32(a0, qf[ks], s0);
+      s1 = DT<T>::mfma32(a1, qf[ks], s1);
+    }
+    float sv[32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      sv[i] = s0[i];
+      sv[16 + i] = s1[i];
+    }
+
+    // ---- masks (edge tiles only) and the row maximum, in the exp2 domain
+    float mx;
+    if constexpr (!EDGE) {
+      mx = fmaxf(fmaxf(sv[0], sv[1]), sv[2]);
+#pragma unroll
+      for (int i = 3; i + 1 < 32; i += 2) mx = fmaxf(fmaxf(mx, sv[i]), sv[i + 1]);
+      mx = fmaxf(mx, sv[31]) * c2;
+    } else {
+      const int64_t mrow = (MASK == 0) ? 0
+                                       : ((int64_t)b * p.ms_b + (int64_t)head * p.ms_h + (int64_t)(q_ok ? qrow : 0) * p.ms_q);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const int kv = kv0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
+        float tv = sv[i] * c2;
+        if (MASK == 0) {
+          if ((kv >= p.Sk) || (CAUSAL && (kv + p.k_offset > q_pos))) tv = -INFINITY;
+        } else {
+          if (CAUSAL && (kv + p.k_offset > q_pos)) tv = FA_NEG_FILL_LOG2;
+          if (kv < p.Sk) {
+            if (MASK == MIO_MASK_KEEP_U8) {
+              const uint8_t keep = ((const uint8_t*)p.mask)[mrow + (int64_t)kv * p.ms_k];
+              if (!keep) tv = FA_NEG_FILL_LOG2;
+            } else if (MASK == MIO_MASK_ADD_F32) {
+              tv += ((const float*)p.mask)[mrow + (int64_t)kv * p.ms_k] * FA_LOG2E;
+            }
+          } else {
+            tv = -INFINITY;
+          }
+        }
+        sv[i] = tv;
+      }
+      mx = sv[0];
+#pragma unroll
+      for (int i = 1; i < 32; ++i) mx = fmaxf(mx, sv[i]);
+    }
+    mx = fmaxf(mx, other_half(mx));
+
+    // ---- online softmax update (flash_attention_kernels.py:276-298 with exp -> exp2).  The running maximum
+    // is only raised -- and O rescaled -- when some row of the wave outgrows it by more than FA_RESCALE_THR
+    // (exp2 domain): until then P is computed against the stale maximum and is at most 2^THR, exact in the
+    // fp32 row sum and harmless in bf16/fp16 (their relative precision does not depend on the scale).
+    float m_sub;
+    if (__builtin_amdgcn_ballot_w64(mx > m_i + FA_RESCALE_THR) != 0) {
+      const float m_new = fmaxf(m_i, mx);
+      m_sub = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = fast_exp2(m_i - m_sub);
+      l_i *= alpha;
+      m_i = m_new;
+#pragma unroll
+      for (int dt = 0; dt < DT_; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+    } else {
+      m_sub = m_i;  // finite here: a row with m_i == -inf always takes the branch above
+    }
+    float rs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float e = EDGE ? fast_exp2(sv[i] - m_sub) : fast_exp2(__builtin_fmaf(sv[i], c2, -m_sub));
+      sv[i] = e;
+      rs += e;
+    }
+    l_i += rs;
+
+    // ---- P^T fragments: k-step s (16 keys) = accumulator registers 8(s&1)..+7 of tile s>>1
+    X8 pf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x4_t w;
+      w[0] = pack2<T>(sv[8 * s + 0], sv[8 * s + 1]);
+      w[1] = pack2<T>(sv[8 * s + 2], sv[8 * s + 3]);
+      w[2] = pack2<T>(sv[8 * s + 4], sv[8 * s + 5]);
+      w[3] = pack2<T>(sv[8 * s + 6], sv[8 * s + 7]);
+      pf[s] = __builtin_bit_cast(X8, w);
+    }
+
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int dt = 0; dt < DT_; ++dt) {
+        const X4 lo = DT<T>::ds_read_tr(vb + v_rd + ((2 * s + 0) * DT_ + dt) * 512);
+        const X4 hi = DT<T>::ds_read_tr(vb + v_rd + ((2 * s + 1) * DT_ + dt) * 512);
+        X8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+        oacc[dt] = DT<T>::mfma32(vf, pf[s], oacc[dt]);
+      }
+    }
+  };
+
   for (int t = 0; t < n_tiles; ++t) {
     const int cur = t & 1;
     const bool more = (t + 1 < n_tiles);
     if (more) stage_load(t + 1);
 
     const int kv0 = t * FA_BN;
-    bool skip = false;
+    bool skip = false, edge = (MASK != 0) || (kv0 + FA_BN > p.Sk);
     if (CAUSAL && MASK == 0) {
       // every key of this tile is in the future of every row of this wave
       skip = (kv0 + p.k_offset) > (q0 + wave * 32 + 31 + p.q_offset);
+      edge = edge || ((kv0 + FA_BN - 1 + p.k_offset) > (q0 + wave * 32 + p.q_offset));
     }
     if (!skip) {
-      const char* kb = smem + cur * SM::STAGE;
-      const char* vb = kb + SM::K_BYTES;
-
-      // ---- S^T = K . Q^T   (two 32-key tiles)
-      f32x16_t s0, s1;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        s0[i] = 0.f;
-        s1[i] = 0.f;
-      }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const X8 a0 = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + k_rd + 32 * ks));
-        const X8 a1 = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + k_rd + 32 * SM::KROW + 32 * ks));
-        s0 = DT<T>::mfma32(a0, qf[ks], s0);
-        s1 = DT<T>::mfma32(a1, qf[ks], s1);
-      }
-
-      // ---- scores -> exp2 domain, masks
-      float sv[32];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        sv[i] = s0[i];
-        sv[16 + i] = s1[i];
-      }
-      float mx;
-      if (MASK == 0) {
-        bool need_causal = false, need_bound = (kv0 + FA_BN > p.Sk);
-        if (CAUSAL) need_causal = (kv0 + FA_BN - 1 + p.k_offset) > (q0 + wave * 32 + p.q_offset);
-        if (need_causal || need_bound) {
-#pragma unroll
-          for (int i = 0; i < 32; ++i) {
-            const int kv = kv0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
-            const bool dead = (kv >= p.Sk) || (CAUSAL && (kv + p.k_offset > q_pos));
-            if (dead) sv[i] = -INFINITY;
-          }
-        }
-        mx = sv[0];
-#pragma unroll
-        for (int i = 1; i < 32; ++i) mx = fmaxf(mx, sv[i]);
-        mx *= c2;
-      } else {
-        const int64_t mrow = (int64_t)b * p.ms_b + (int64_t)head * p.ms_h + (int64_t)(q_ok ? qrow : 0) * p.ms_q;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-          const int kv = kv0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
-          float tv = sv[i] * c2;
-          if (CAUSAL && (kv + p.k_offset > q_pos)) tv = FA_NEG_FILL_LOG2;
-          if (kv < p.Sk) {
-            if (MASK == MIO_MASK_KEEP_U8) {
-              const uint8_t keep = ((const uint8_t*)p.mask)[mrow + (int64_t)kv * p.ms_k];
-              if (!keep) tv = FA_NEG_FILL_LOG2;
-            } else {
-              tv += ((const float*)p.mask)[mrow + (int64_t)kv * p.ms_k] * FA_LOG2E;
-            }
-          } else {
-            tv = -INFINITY;
-          }
-          sv[i] = tv;
-        }
-        mx = sv[0];
-#pragma unroll
-        for (int i = 1; i < 32; ++i) mx = fmaxf(mx, sv[i]);
-      }
-      mx = fmaxf(mx, other_half(mx));
-
-      // ---- online softmax update (flash_attention_kernels.py:276-298 with exp -> exp2)
-      const float m_new = fmaxf(m_i, mx);
-      const float m_sub = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = fast_exp2(m_i - m_sub);
-      float rs = 0.f;
-#pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const float e = (MASK == 0) ? fast_exp2(__builtin_fmaf(sv[i], c2, -m_sub)) : fast_exp2(sv[i] - m_sub);
-        sv[i] = e;
-        rs += e;
-      }
-      l_i = l_i * alpha + rs;
-      m_i = m_new;
-#pragma unroll
-      for (int dt = 0; dt < DT_; ++dt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
-
-      // ---- P^T fragments: k-step s (16 keys) = accumulator registers 8(s&1)..+7 of tile s>>1
-      X8 pf[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        u32x4_t w;
-        w[0] = pack2<T>(sv[8 * s + 0], sv[8 * s + 1]);
-        w[1] = pack2<T>(sv[8 * s + 2], sv[8 * s + 3]);
-        w[2] = pack2<T>(sv[8 * s + 4], sv[8 * s + 5]);
-        w[3] = pack2<T>(sv[8 * s + 6], sv[8 * s + 7]);
-        pf[s] = __builtin_bit_cast(X8, w);
-      }
-
-      // ---- O^T += V^T . P^T
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int dt = 0; dt < DT_; ++dt) {
-          const X4 lo = DT<T>::ds_read_tr(vb + v_rd + ((2 * s + 0) * DT_ + dt) * 512);
-          const X4 hi = DT<T>::ds_read_tr(vb + v_rd + ((2 * s + 1) * DT_ + dt) * 512);
-          X8 vf;
-          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-          vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-          oacc[dt] = DT<T>::mfma32(vf, pf[s], oacc[dt]);
-        }
-      }
+      if (edge) process_tile(t, std::true_type{});
+      else process_tile(t, std::false_type{});
     }
 
     if (more) stage_write(cur ^ 1);
