@@ -46,38 +46,47 @@ def _events_ms(fn, iters, warmup=3):
     return s.elapsed_time(e) / iters
 
 
-def kernel_rooflines(B, S, d, H, I, dt, iters=10):
-    """Per-kernel time of one layer's launches at the benchmark shape -> which kernel dominates, and its
-    achieved fraction of the MFMA roofline (algorithmic FLOPs, SURVEY.md 8d / BASELINE.md section 4)."""
+def kernel_rooflines(model, x, iters=10):
+    """Per-kernel time of ONE layer's launches on the layer's real weights and activations (layer 0 of the
+    benchmark stack, so the operand statistics -- and with them the clock the chip holds -- are the model's own),
+    HIP events on the launch stream -> which kernel dominates and its achieved fraction of the MFMA roofline
+    (algorithmic FLOPs: SURVEY.md 8d / BASELINE.md section 4)."""
     from mio import ops
 
-    dev, M, D = "cuda", B * S, d // H
-    q, k, v = (torch.randn(B, S, H, D, device=dev, dtype=dt) for _ in range(3))
+    blk = model.h[0]
+    B, S, d = x.shape
+    H = blk.attn.num_attention_heads
+    D = d // H
+    M = B * S
+    wqkv, bqkv = blk.attn.qkv_proj.weight, blk.attn.qkv_proj.bias
+    wo, bo = blk.attn.o_proj.weight, blk.attn.o_proj.bias
+    w1, b1 = blk.mlp.mlp.fc1.weight, blk.mlp.mlp.fc1.bias
+    w2, b2 = blk.mlp.mlp.fc2.weight, blk.mlp.mlp.fc2.bias
+    I = w1.shape[0]
+    ln1 = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
+    qkv = ops.gemm_bias_act(ln1, wqkv, bqkv)
+    q = qkv[:, :, :d].view(B, S, H, D)
+    k = qkv[:, :, d:2 * d].view(B, S, H, D)
+    v = qkv[:, :, 2 * d:].view(B, S, H, D)
+    ctx = ops.fa3_fwd(q, k, v, causal=True).view(B, S, d)
+    att = ops.gemm_bias_act(ctx, wo, bo, residual=x)
+    ln2 = ops.layernorm(att, blk.ln_2.weight, blk.ln_2.bias)
+    hid = ops.gemm_bias_act(ln2, w1, b1, "gelu")
+    o3, o1, oI = torch.empty_like(qkv), torch.empty_like(att), torch.empty_like(hid)
     out = {}
     t = _events_ms(lambda: ops.fa3_fwd(q, k, v, causal=True), iters)
     out["fa3_fwd_kernel<bf16,D64,causal>"] = dict(ms=t, launches=1, flops=2.0 * B * S * (S + 1) * d)
-    x = torch.randn(M, d, device=dev, dtype=dt)
-    h = torch.randn(M, I, device=dev, dtype=dt)
-    wqkv = (torch.randn(3 * d, d, device=dev) * 0.02).to(dt)
-    wo = (torch.randn(d, d, device=dev) * 0.02).to(dt)
-    w1 = (torch.randn(I, d, device=dev) * 0.02).to(dt)
-    w2 = (torch.randn(d, I, device=dev) * 0.02).to(dt)
-    b3, b1, bI = (torch.zeros(n, device=dev, dtype=dt) for n in (3 * d, d, I))
-    o3 = torch.empty(M, 3 * d, device=dev, dtype=dt)
-    o1 = torch.empty(M, d, device=dev, dtype=dt)
-    oI = torch.empty(M, I, device=dev, dtype=dt)
 
     def gemm_none():  # the three ACT_NONE launches of a layer: qkv, out-proj(+res), fc2(+res)
-        ops.gemm_bias_act(x, wqkv, b3, out=o3)
-        ops.gemm_bias_act(x, wo, b1, residual=x, out=o1)
-        ops.gemm_bias_act(h, w2, b1, residual=x, out=o1)
+        ops.gemm_bias_act(ln1, wqkv, bqkv, out=o3)
+        ops.gemm_bias_act(ctx, wo, bo, residual=x, out=o1)
+        ops.gemm_bias_act(hid, w2, b2, residual=att, out=o1)
 
     t = _events_ms(gemm_none, iters)
-    out["gemm_bias_act_kernel<bf16,256x256,none>"] = dict(ms=t, launches=3, flops=2.0 * M * d * (3 * d + d + I))
-    t = _events_ms(lambda: ops.gemm_bias_act(x, w1, bI, "gelu", out=oI), iters)
-    out["gemm_bias_act_kernel<bf16,256x256,gelu>"] = dict(ms=t, launches=1, flops=2.0 * M * d * I)
-    lw = torch.ones(d, device=dev, dtype=dt)
-    t = _events_ms(lambda: ops.layernorm(x, lw, lw), iters)
+    out["gemm4w16_kernel<bf16,none>"] = dict(ms=t, launches=3, flops=2.0 * M * d * (3 * d + d + I))
+    t = _events_ms(lambda: ops.gemm_bias_act(ln2, w1, b1, "gelu", out=oI), iters)
+    out["gemm4w16_kernel<bf16,gelu_tanh>"] = dict(ms=t, launches=1, flops=2.0 * M * d * I)
+    t = _events_ms(lambda: ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias), iters)
     out["layernorm_kernel<bf16>"] = dict(ms=2 * t, launches=2, bytes=2 * 2.0 * M * d * 2)
     return out
 
@@ -170,7 +179,7 @@ def main():
 
     if not a.no_extra and rank == 0 and N == 1:
         try:
-            ks = kernel_rooflines(B, S, d, H, I, dt)
+            ks = kernel_rooflines(model, x)
             dom = max((k for k in ks if "flops" in ks[k]), key=lambda k: ks[k]["ms"])
             kd = ks[dom]
             per_launch_ms = kd["ms"] / kd["launches"]

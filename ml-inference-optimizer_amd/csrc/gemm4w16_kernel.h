@@ -15,7 +15,7 @@
 //   * LDS holds FOUR K-tiles (4 x (X[256][32] + W[256][32]) = 128 KiB): a 256x256 tile needs ~32 B/clk/CU of
 //     operands at full rate and one CU's fill path is latency x concurrency bound, so three K-tiles (96 KiB) stay
 //     in flight behind the one being multiplied; loads are never drained (counted s_waitcnt vmcnt(16)).
-//   * direct-to-LDS loads (global_load_lds_dwordx4): a 1-KiB piece = 16 rows x 64 B.  Bank swizzle for the
+//   * direct-to-LDS loads (buffer_load_dwordx4 ... lds): a 1-KiB piece = 16 rows x 64 B.  Bank swizzle for the
 //     16x16x32 fragment read (lane -> row l&15, 16-byte chunk l>>4): chunk c of row r is stored at
 //     c ^ f((r>>2)&3), f = {0,2,3,1}, applied to the per-lane SOURCE address (LDS-DMA writes lane-linear).
 //   * ONE barrier per K-tile, in the middle of its 64 MFMAs: first half = MFMAs + the 8 prefetch pieces of
@@ -108,7 +108,8 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmDev& p, int64_t mbase,
   row_pair(std::integral_constant<int, 2>{}); row_pair(std::integral_constant<int, 3>{});
 }
 
-// VAR (timing-only ablations, 0 in the shipped dispatch): 16 = no per-K-tile barrier (racy, wrong results)
+// VAR (timing-only ablations, 0 in the shipped dispatch): 4 = no prefetch issue in the loop, 8 = no fragment
+// reads in the loop, 16 = no per-K-tile barrier (all: wrong results), 32 = in-kernel stamps (diagnostic build)
 template <typename T, int ACT, int VAR = 0>
 __global__ __launch_bounds__(256) void gemm4w16_kernel(const GemmDev p) {
   using X8 = typename DT<T>::x8;
@@ -126,24 +127,28 @@ __global__ __launch_bounds__(256) void gemm4w16_kernel(const GemmDev p) {
   const int n0 = tn * 256;
   const int nk = (p.K + G6_BK - 1) / G6_BK;
 
-  // ---- prefetch addressing: an operand tile is 16 pieces of 16 rows x 64 B; wave w owns pieces 4w..4w+3 of X and W
+  // ---- prefetch addressing: an operand tile is 16 pieces of 16 rows x 64 B; wave w owns pieces 4w..4w+3 of X and W.
+  // Loads are buffer_load ... lds with a per-workgroup resource (base = first row of this tile), a per-lane
+  // 32-bit byte offset fixed for the whole kernel (clamped row * ld + swizzled chunk) and the K offset in an
+  // SGPR: no vector ALU work per load (one wave per SIMD: every VALU instruction between two MFMAs delays the
+  // second one -- measured 31 cycles per load with 64-bit per-lane addresses).  Requires K % 32 == 0.
   const int prow = lane >> 2, pcs = lane & 3;
-  int64_t xoff[4], woff[4];
-  int kch[4];
+  int xvo[4], wvo[4];
+  const int64_t mrem = p.M - m0;          // rows of x left from this tile's first row (>= 1)
+  const int nrem = p.N - n0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (wave * 4 + i) * 16 + prow;  // 0..255
-    kch[i] = pcs ^ g6_swz(row);
-    int64_t gm = m0 + row;
-    if (gm > p.M - 1) gm = p.M - 1;
-    xoff[i] = gm * p.ldx + 8 * kch[i];
-    int gn = n0 + row;
-    if (gn > p.N - 1) gn = p.N - 1;
-    woff[i] = (int64_t)gn * p.ldw + 8 * kch[i];
+    const int kch = pcs ^ g6_swz(row);
+    const int xr = (row < mrem) ? row : (int)(mrem - 1);
+    const int wrw = (row < nrem) ? row : (nrem - 1);
+    xvo[i] = xr * (int)p.ldx * 2 + 16 * kch;
+    wvo[i] = wrw * (int)p.ldw * 2 + 16 * kch;
   }
-  const T* xg = (const T*)p.x;
-  const T* wg = (const T*)p.w;
-  const bool ktail = (p.K % G6_BK) != 0;
+  const __amdgpu_buffer_rsrc_t xrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.x + m0 * p.ldx), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.w + (int64_t)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
 
   // issue ONE 1-KiB piece (piece i of X if which == 0, of W if which == 1) of K-tile kt into stage kt % 4.
   // Branch-free: past the last K-tile the last one is simply re-fetched into an idle stage.
@@ -151,10 +156,9 @@ __global__ __launch_bounds__(256) void gemm4w16_kernel(const GemmDev p) {
     constexpr int i = decltype(I)::value, which = decltype(WHICH)::value;
     const int kte = kt < nk ? kt : nk - 1;
     char* dst = smem + (kt & (G6_STAGES - 1)) * G6_BUF + which * G6_XT + (wave * 4 + i) * 1024;
-    const int k0 = kte * G6_BK;
-    const T* src = (which ? wg + woff[i] : xg + xoff[i]) + k0;
-    if (ktail && k0 + 8 * kch[i] >= p.K) src = (const T*)mio_zero16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (MIO_LDS void*)dst, 16, 0, 0);
+    const int koff = kte * (G6_BK * 2);  // bytes
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? wrs : xrs, (MIO_LDS void*)dst, 16, which ? wvo[i] : xvo[i], koff,
+                                             0, 0);
   };
 
   // 64 accumulator tiles of 4 registers live in the accumulator file a[0:255], owned by inline asm (tile
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm4w16_kernel(const GemmDev p) {
 #define IC(N) std::integral_constant<int, N>{}
 #define G6_MFMA_W(J)                                                   \
     mfma4(RB{}, IC(J));                                                \
-    if constexpr ((J) % 2 == 0 && (J) / 2 + 1 < 8) read_w(buf, IC((J) / 2 + 1));
+    if constexpr (!(VAR & 8) && (J) % 2 == 0 && (J) / 2 + 1 < 8) read_w(buf, IC((J) / 2 + 1));
     G6_MFMA_W(0) __builtin_amdgcn_sched_barrier(0);
     G6_MFMA_W(1) __builtin_amdgcn_sched_barrier(0);
     G6_MFMA_W(2) __builtin_amdgcn_sched_barrier(0);
@@ -248,14 +252,14 @@ __global__ __launch_bounds__(256) void gemm4w16_kernel(const GemmDev p) {
 #define G6_MICRO_B(J, P)                                                                       \
     G6_MFMA_W(J)                                                                               \
     if constexpr ((P) < 8) {                                                                   \
-      issue_one(kt + 3, IC((P) / 2), IC((P) % 2));                                             \
-      read_x(nbuf, NRB{}, IC((P) < 8 ? (P) : 0));                                              \
+      if constexpr (!(VAR & 4)) issue_one(kt + 3, IC((P) / 2), IC((P) % 2));                   \
+      if constexpr (!(VAR & 8)) read_x(nbuf, NRB{}, IC((P) < 8 ? (P) : 0));                    \
     }                                                                                          \
     __builtin_amdgcn_sched_barrier(0);
     G6_MICRO_B(4, 0) G6_MICRO_B(5, 1) G6_MICRO_B(6, 2) G6_MICRO_B(7, 3) G6_MICRO_B(8, 4) G6_MICRO_B(9, 5)
     G6_MICRO_B(10, 6) G6_MICRO_B(11, 7) G6_MICRO_B(12, 8) G6_MICRO_B(13, 8)
     G6_MFMA_W(14)
-    read_w(nbuf, IC(0));  // weight fragment 0 of K-tile kt+1 (fw[0] was last used by nt = 6, micro-steps 12-13)
+    if constexpr (!(VAR & 8)) read_w(nbuf, IC(0));  // weight fragment 0 of K-tile kt+1 (fw[0] was last used by nt = 6, micro-steps 12-13)
     __builtin_amdgcn_sched_barrier(0);
     G6_MFMA_W(15) __builtin_amdgcn_sched_barrier(0);
 #undef G6_MICRO_B

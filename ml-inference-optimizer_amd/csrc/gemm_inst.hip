@@ -96,8 +96,17 @@ static int gemm_var();
 template <int ACT, int VAR = 0>
 static int launch_4w16(GemmDev p, hipStream_t stream) {
   if constexpr (ACT == MIO_ACT_NONE && VAR == 0) {
+    if (p.dbg != nullptr) {
+      switch (gemm_var()) {
+        case 4: return launch_4w16<ACT, 36>(p, stream);
+        case 8: return launch_4w16<ACT, 40>(p, stream);
+        case 12: return launch_4w16<ACT, 44>(p, stream);
+        case 16: return launch_4w16<ACT, 48>(p, stream);
+        case 28: return launch_4w16<ACT, 60>(p, stream);
+        default: return launch_4w16<ACT, 32>(p, stream);
+      }
+    }
     if (gemm_var() == 16) return launch_4w16<ACT, 16>(p, stream);
-    if (p.dbg != nullptr) return launch_4w16<ACT, 32>(p, stream);
   }
   p.tiles_m = (int)((p.M + 255) / 256);
   p.tiles_n = (p.N + 255) / 256;
@@ -141,6 +150,9 @@ static int launch_act(const GemmDev& p, hipStream_t stream) {
       if (gemm_impl() == 1) return launch_cfg<256, 256, 2, 4, ACT>(p, stream);
       if (gemm_impl() == 2) return launch_8p<ACT>(p, stream);
       if (gemm_impl() == 3) return launch_4w<ACT>(p, stream);
+      // the 16x16x32 kernel addresses operands with 32-bit per-tile byte offsets and needs whole K-tiles
+      const bool fits = (p.K % 32 == 0) && (p.ldx * 512 < (int64_t)0x7fffffff) && (p.ldw * 512 < (int64_t)0x7fffffff);
+      if (!fits) return launch_cfg<256, 256, 2, 4, ACT>(p, stream);
       return launch_4w16<ACT>(p, stream);
     }
     return launch_cfg<128, 128, 2, 2, ACT>(p, stream);

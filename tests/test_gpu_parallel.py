@@ -1,0 +1,124 @@
+"""The distributed wrappers with the REAL HIP kernels: two ranks sharing cuda:0 over gloo (a one-GPU box cannot
+host two RCCL ranks; gloo moves the same tensors through the host).  What is checked is that the kernels, the
+(o, lse) carry, the strided views and the schedules compose correctly on device memory."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, fn_name, args):
+    for p in (ROOT, os.path.join(ROOT, "ml-inference-optimizer_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    torch.set_grad_enabled(False)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        globals()[fn_name](rank, world, *args)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn_name, world=2, args=()):
+    mp.spawn(_worker, args=(world, _free_port(), fn_name, args), nprocs=world, join=True)
+
+
+def _w_ring(rank, world, exchange, causal, zigzag, layout):
+    import oracle
+    from mio.parallelism.sequence_parallel import ring_attention, zigzag_shard
+    torch.manual_seed(1)
+    B, H, S, D = 1, 4, 512 * world, 64
+    dt = torch.float16
+    q, k, v = (torch.randn(B, S, H, D).to(dt) for _ in range(3))
+    ref = oracle.standard_attention(q, k, v, causal=causal)
+    if zigzag:
+        loc = [zigzag_shard(t, rank, world, 1) for t in (q, k, v)]
+        ref_loc = zigzag_shard(ref, rank, world, 1)
+    else:
+        n = S // world
+        loc = [t[:, rank * n:(rank + 1) * n] for t in (q, k, v)]
+        ref_loc = ref[:, rank * n:(rank + 1) * n]
+    loc = [(t.permute(0, 2, 1, 3) if layout == "bhsd" else t).contiguous().cuda() for t in loc]
+    out = ring_attention(*loc, None, layout=layout, causal=causal, zigzag=zigzag, exchange=exchange)
+    out = out.cpu()
+    if layout == "bhsd":
+        out = out.permute(0, 2, 1, 3)
+    refq = ref_loc.to(dt).float()
+    rel = ((out.float() - refq).abs().mean() / refq.abs().mean()).item()
+    assert rel < 1e-3, (exchange, causal, zigzag, layout, rel)
+
+
+def _w_tp(rank, world):
+    import oracle
+    from mio.parallelism import TensorParallelConfig, TensorParallelMLP, TensorParallelAttention
+    torch.manual_seed(0)
+    d, I, H, B, S = 256, 1024, 4, 2, 640
+    dt = torch.bfloat16
+    cfg = TensorParallelConfig(world_size=world, tp_size=world, overlap_chunks=3)
+    x = torch.randn(B, S, d).to(dt)
+    res = torch.randn(B, S, d).to(dt)
+    w1, b1 = (torch.randn(I, d) * .05).to(dt), (torch.randn(I) * .05).to(dt)
+    w2, b2 = (torch.randn(d, I) * .05).to(dt), (torch.randn(d) * .05).to(dt)
+    mlp = TensorParallelMLP(d, I, cfg, activation="gelu").to("cuda", dt)
+    per = I // world
+    mlp.dense_h_to_4h.weight.copy_(w1[rank * per:(rank + 1) * per]); mlp.dense_h_to_4h.bias.copy_(b1[rank * per:(rank + 1) * per])
+    mlp.dense_4h_to_h.weight.copy_(w2[:, rank * per:(rank + 1) * per]); mlp.dense_4h_to_h.bias.copy_(b2)
+    y = mlp(x.cuda(), residual=res.cuda()).cpu()
+    ref = oracle.fused_mlp(x, w1, b1, w2, b2, "gelu", residual=res)
+    rel = ((y.double() - ref).abs().mean() / ref.abs().mean()).item()
+    assert rel < 1.5e-2, rel
+    att = TensorParallelAttention(d, H, cfg, causal=True).to("cuda", dt)
+    ws = [(torch.randn(d, d) * .05).to(dt) for _ in range(4)]
+    bs = [(torch.randn(d) * .05).to(dt) for _ in range(4)]
+    pd = d // world
+    for lin, w, b in zip((att.query, att.key, att.value), ws, bs):
+        lin.weight.copy_(w[rank * pd:(rank + 1) * pd]); lin.bias.copy_(b[rank * pd:(rank + 1) * pd])
+    att.output.weight.copy_(ws[3][:, rank * pd:(rank + 1) * pd]); att.output.bias.copy_(bs[3])
+    y = att(x.cuda()).cpu()
+    F = torch.nn.functional
+    q, k, v = (F.linear(x.double(), w.double(), b.double()).view(B, S, H, d // H) for w, b in zip(ws[:3], bs[:3]))
+    ref = F.linear(oracle.standard_attention(q, k, v, causal=True).reshape(B, S, d), ws[3].double(), bs[3].double())
+    rel = ((y.double() - ref).abs().mean() / ref.abs().mean()).item()
+    assert rel < 1.5e-2, rel
+
+
+def _w_bench_extras(rank, world):
+    """The exact code bench.py runs for its multi-GPU 'extra' block, at a small size (plumbing check)."""
+    from tools.bench_parallel import bench_ring, bench_tp
+    r = bench_tp(world, 2, 256, 256, 4, 1024, 2, torch.bfloat16, steps=1, warmup=1)
+    assert r["overlapped"]["tokens_per_s"] > 0 and r["unoverlapped"]["tokens_per_s"] > 0
+    r = bench_ring(world, 1024 * world, 256, 4, torch.bfloat16, steps=1, warmup=1)
+    assert all(r[k]["tokens_per_s"] > 0 for k in ("noncausal_mesh", "noncausal_ring", "causal_zigzag_mesh"))
+
+
+@pytest.mark.parametrize("exchange,causal,zigzag,layout", [
+    ("mesh", False, False, "bhsd"), ("ring", False, False, "bshd"), ("ring", True, False, "bhsd"),
+    ("mesh", True, True, "bshd"),
+])
+def test_ring_attention_hip_ws2(exchange, causal, zigzag, layout):
+    _run("_w_ring", 2, (exchange, causal, zigzag, layout))
+
+
+def test_tensor_parallel_hip_ws2():
+    _run("_w_tp", 2)
+
+
+def test_bench_extras_hip_ws2():
+    _run("_w_bench_extras", 2)

@@ -15,7 +15,8 @@ def _sync():
 
 
 def _max_over_ranks(t):
-    x = torch.tensor([t], device="cuda", dtype=torch.float64)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    x = torch.tensor([t], device=dev, dtype=torch.float64)
     dist.all_reduce(x, op=dist.ReduceOp.MAX)
     return float(x.item())
 
