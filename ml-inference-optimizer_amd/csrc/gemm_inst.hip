@@ -2,6 +2,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "gemm2x_kernel.h"
 #include "gemm4w16_kernel.h"
 #include "gemm4w_kernel.h"
 #include "gemm8p_kernel.h"
@@ -123,6 +124,23 @@ static int launch_4w16(GemmDev p, hipStream_t stream) {
   return 0;
 }
 
+template <int ACT>
+static int launch_2x(GemmDev p, hipStream_t stream) {
+  p.tiles_m = (int)((p.M + 255) / 256);
+  p.tiles_n = (p.N + 127) / 128;
+  auto kern = gemm2x_kernel<GT, ACT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
+    if (e != hipSuccess) return mio_fail(std::string("gemm2x: hipFuncSetAttribute: ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), G2_SMEM, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("gemm2x launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
 // MIO_GEMM_IMPL=v1|8p selects an older pipeline for A/B comparisons (read once); default = 4-wave kernel.
 static int gemm_impl() {
   static const int v = [] {
@@ -131,6 +149,7 @@ static int gemm_impl() {
     if (std::string(e) == "v1") return 1;
     if (std::string(e) == "8p") return 2;
     if (std::string(e) == "4w") return 3;
+    if (std::string(e) == "2x") return 4;
     return 0;
   }();
   return v;
@@ -153,6 +172,7 @@ static int launch_act(const GemmDev& p, hipStream_t stream) {
       // the 16x16x32 kernel addresses operands with 32-bit per-tile byte offsets and needs whole K-tiles
       const bool fits = (p.K % 32 == 0) && (p.ldx * 512 < (int64_t)0x7fffffff) && (p.ldw * 512 < (int64_t)0x7fffffff);
       if (!fits) return launch_cfg<256, 256, 2, 4, ACT>(p, stream);
+      if (gemm_impl() == 4) return launch_2x<ACT>(p, stream);
       return launch_4w16<ACT>(p, stream);
     }
     return launch_cfg<128, 128, 2, 2, ACT>(p, stream);
