@@ -140,6 +140,18 @@ __global__ __launch_bounds__(256) void fa3_fwd_kernel(const FaDev p) {
     }
   }
 
+  // Consume the Q fragments (and the carried state) here: hipcc then places its wait for those loads HERE instead
+  // of at their first use inside the tile loop, where a vmcnt(0) would also drain the K/V prefetch of every tile.
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
+  if (p.carry_in) {
+#pragma unroll
+    for (int dt = 0; dt < DT_; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) asm volatile("" ::"v"(oacc[dt][i]));
+    asm volatile("" ::"v"(m_i));
+  }
+
   // ---- number of KV tiles this workgroup visits
   int n_tiles;
   if (CAUSAL && MASK == 0) {
@@ -155,38 +167,53 @@ __global__ __launch_bounds__(256) void fa3_fwd_kernel(const FaDev p) {
   const T* vbase = (const T*)p.v + b * p.vs_b + kvh * p.vs_h;
   u32x4_t kreg[NLD], vreg[NLD];
 
+  // Loads are UNCONDITIONAL (row / chunk clamped to a valid address): a load under `if (ok)` merges with the
+  // zero default at the join, which is a use of the loaded register, so hipcc waits for the load right there --
+  // at the top of the tile, with its whole HBM/L2 latency exposed.  Out-of-range rows / chunks are zeroed when
+  // the registers are written to LDS (after the tile's MFMA work), and only for tiles that need it.
+  const int d_chunks = p.D >> 3;  // valid 16-byte chunks per row
   auto stage_load = [&](int tile) {
     const int kv0 = tile * FA_BN;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int i = tid + 256 * j;
       const int row = i / CPR, c = i % CPR;
-      const int kv = kv0 + row;
-      const bool ok = (kv < p.Sk) && (8 * c < p.D);
-      u32x4_t zk = {0, 0, 0, 0}, zv = {0, 0, 0, 0};
-      if (ok) {
-        zk = *(const u32x4_t*)(kbase + (int64_t)kv * p.ks_s + 8 * c);
-        zv = *(const u32x4_t*)(vbase + (int64_t)kv * p.vs_s + 8 * c);
-      }
-      kreg[j] = zk;
-      vreg[j] = zv;
+      int kv = kv0 + row;
+      kv = kv < p.Sk ? kv : p.Sk - 1;
+      const int cc = c < d_chunks ? c : d_chunks - 1;
+      // asm loads: invisible to hipcc's s_waitcnt insertion, which would otherwise drain them (vmcnt(0)) at the
+      // first basic-block join of the tile body, i.e. before the first MFMA.  Retired by fa_wait_loads() below.
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kreg[j]) : "v"(kbase + (int64_t)kv * p.ks_s + 8 * cc) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vreg[j]) : "v"(vbase + (int64_t)kv * p.vs_s + 8 * cc) : "memory");
     }
   };
-  auto stage_write = [&](int buf) {
+  auto wait_loads = [&]() {  // every staged register is an in/out operand: no consumer can be scheduled above this
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(kreg[j]), "+v"(vreg[j])::"memory");
+  };
+  auto stage_write = [&](int buf, int tile) {
+    wait_loads();
     char* kb = smem + buf * SM::STAGE;
     char* vb = kb + SM::K_BYTES;
+    const int kv0 = tile * FA_BN;
+    const bool partial = (kv0 + FA_BN > p.Sk) || (d_chunks != CPR);  // wave-uniform
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int i = tid + 256 * j;
       const int row = i / CPR, c = i % CPR;
-      *(u32x4_t*)(kb + row * SM::KROW + 16 * c) = kreg[j];
-      *(u32x4_t*)(vb + ((row >> 3) * DT_ + (c >> 2)) * 512 + (row & 7) * 64 + (c & 3) * 16) = vreg[j];
+      u32x4_t kk = kreg[j], vv = vreg[j];
+      if (partial && !((kv0 + row < p.Sk) && (c < d_chunks))) {
+        kk = (u32x4_t){0, 0, 0, 0};
+        vv = (u32x4_t){0, 0, 0, 0};
+      }
+      *(u32x4_t*)(kb + row * SM::KROW + 16 * c) = kk;
+      *(u32x4_t*)(vb + ((row >> 3) * DT_ + (c >> 2)) * 512 + (row & 7) * 64 + (c & 3) * 16) = vv;
     }
   };
 
   if (n_tiles > 0) {
     stage_load(0);
-    stage_write(0);
+    stage_write(0, 0);
   }
   __syncthreads();
 
@@ -206,61 +233,74 @@ __global__ __launch_bounds__(256) void fa3_fwd_kernel(const FaDev p) {
     const char* kb = smem + cur * SM::STAGE;
     const char* vb = kb + SM::K_BYTES;
 
-    // ---- S^T = K . Q^T   (two 32-key tiles)
-    f32x16_t s0, s1;
+    // ---- S^T = K . Q^T   (two 32-key tiles).  Everything below works on the two accumulator tuples in place
+    // (sc[tt][reg]); copying them into a scalar array costs 32 v_mov_b64 per tile in a VALU-bound loop.
+    f32x16_t sc[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      s0[i] = 0.f;
-      s1[i] = 0.f;
+      sc[0][i] = 0.f;
+      sc[1][i] = 0.f;
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const X8 a0 = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + k_rd + 32 * ks));
       const X8 a1 = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + k_rd + 32 * SM::KROW + 32 * ks));
-      s0 = DT<T>::mfma32(a0, qf[ks], s0);
-      s1 = DT<T>::mfma32(a1, qf[ks], s1);
+      sc[0] = DT<T>::mfma32(a0, qf[ks], sc[0]);
+      sc[1] = DT<T>::mfma32(a1, qf[ks], sc[1]);
     }
-    float sv[32];
+
+    // ---- V^T fragments for the whole tile, issued NOW: the transposed LDS reads fly under the softmax VALU work
+    // below instead of each stalling the P.V MFMA it feeds (hipcc otherwise sinks every read to just before its use)
+    X8 vfr[4][DT_];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      sv[i] = s0[i];
-      sv[16 + i] = s1[i];
-    }
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int dt = 0; dt < DT_; ++dt) {
+        const X4 lo = DT<T>::ds_read_tr(vb + v_rd + ((2 * s + 0) * DT_ + dt) * 512);
+        const X4 hi = DT<T>::ds_read_tr(vb + v_rd + ((2 * s + 1) * DT_ + dt) * 512);
+        vfr[s][dt][0] = lo[0]; vfr[s][dt][1] = lo[1]; vfr[s][dt][2] = lo[2]; vfr[s][dt][3] = lo[3];
+        vfr[s][dt][4] = hi[0]; vfr[s][dt][5] = hi[1]; vfr[s][dt][6] = hi[2]; vfr[s][dt][7] = hi[3];
+      }
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- masks (edge tiles only) and the row maximum, in the exp2 domain
     float mx;
     if constexpr (!EDGE) {
-      mx = fmaxf(fmaxf(sv[0], sv[1]), sv[2]);
+      mx = fmaxf(fmaxf(sc[0][0], sc[0][1]), sc[0][2]);
 #pragma unroll
-      for (int i = 3; i + 1 < 32; i += 2) mx = fmaxf(fmaxf(mx, sv[i]), sv[i + 1]);
-      mx = fmaxf(mx, sv[31]) * c2;
+      for (int i = 3; i + 1 < 16; i += 2) mx = fmaxf(fmaxf(mx, sc[0][i]), sc[0][i + 1]);
+      mx = fmaxf(fmaxf(mx, sc[0][15]), sc[1][0]);
+#pragma unroll
+      for (int i = 1; i + 1 < 16; i += 2) mx = fmaxf(fmaxf(mx, sc[1][i]), sc[1][i + 1]);
+      mx = fmaxf(mx, sc[1][15]) * c2;
     } else {
       const int64_t mrow = (MASK == 0) ? 0
                                        : ((int64_t)b * p.ms_b + (int64_t)head * p.ms_h + (int64_t)(q_ok ? qrow : 0) * p.ms_q);
+      mx = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const int kv = kv0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
-        float tv = sv[i] * c2;
-        if (MASK == 0) {
-          if ((kv >= p.Sk) || (CAUSAL && (kv + p.k_offset > q_pos))) tv = -INFINITY;
-        } else {
-          if (CAUSAL && (kv + p.k_offset > q_pos)) tv = FA_NEG_FILL_LOG2;
-          if (kv < p.Sk) {
-            if (MASK == MIO_MASK_KEEP_U8) {
-              const uint8_t keep = ((const uint8_t*)p.mask)[mrow + (int64_t)kv * p.ms_k];
-              if (!keep) tv = FA_NEG_FILL_LOG2;
-            } else if (MASK == MIO_MASK_ADD_F32) {
-              tv += ((const float*)p.mask)[mrow + (int64_t)kv * p.ms_k] * FA_LOG2E;
-            }
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int kv = kv0 + 32 * tt + (i & 3) + 8 * (i >> 2) + 4 * h;
+          float tv = sc[tt][i] * c2;
+          if (MASK == 0) {
+            if ((kv >= p.Sk) || (CAUSAL && (kv + p.k_offset > q_pos))) tv = -INFINITY;
           } else {
-            tv = -INFINITY;
+            if (CAUSAL && (kv + p.k_offset > q_pos)) tv = FA_NEG_FILL_LOG2;
+            if (kv < p.Sk) {
+              if (MASK == MIO_MASK_KEEP_U8) {
+                const uint8_t keep = ((const uint8_t*)p.mask)[mrow + (int64_t)kv * p.ms_k];
+                if (!keep) tv = FA_NEG_FILL_LOG2;
+              } else if (MASK == MIO_MASK_ADD_F32) {
+                tv += ((const float*)p.mask)[mrow + (int64_t)kv * p.ms_k] * FA_LOG2E;
+              }
+            } else {
+              tv = -INFINITY;
+            }
           }
+          sc[tt][i] = tv;
+          mx = fmaxf(mx, tv);
         }
-        sv[i] = tv;
-      }
-      mx = sv[0];
-#pragma unroll
-      for (int i = 1; i < 32; ++i) mx = fmaxf(mx, sv[i]);
     }
     mx = fmaxf(mx, other_half(mx));
 
@@ -282,40 +322,33 @@ __global__ __launch_bounds__(256) void fa3_fwd_kernel(const FaDev p) {
     } else {
       m_sub = m_i;  // finite here: a row with m_i == -inf always takes the branch above
     }
-    float rs = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const float e = EDGE ? fast_exp2(sv[i] - m_sub) : fast_exp2(__builtin_fmaf(sv[i], c2, -m_sub));
-      sv[i] = e;
-      rs += e;
-    }
-    l_i += rs;
-
-    // ---- P^T fragments: k-step s (16 keys) = accumulator registers 8(s&1)..+7 of tile s>>1
+    // P = exp2(score - m), row sum, and the P^T fragments: k-step s (16 keys) = registers 8(s&1)..+7 of tile s>>1
+    float rs0 = 0.f, rs1 = 0.f;
     X8 pf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      float e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = sc[s >> 1][8 * (s & 1) + j];
+        e[j] = EDGE ? fast_exp2(x - m_sub) : fast_exp2(__builtin_fmaf(x, c2, -m_sub));
+      }
+      rs0 += (e[0] + e[1]) + (e[2] + e[3]);
+      rs1 += (e[4] + e[5]) + (e[6] + e[7]);
       u32x4_t w;
-      w[0] = pack2<T>(sv[8 * s + 0], sv[8 * s + 1]);
-      w[1] = pack2<T>(sv[8 * s + 2], sv[8 * s + 3]);
-      w[2] = pack2<T>(sv[8 * s + 4], sv[8 * s + 5]);
-      w[3] = pack2<T>(sv[8 * s + 6], sv[8 * s + 7]);
+      w[0] = pack2<T>(e[0], e[1]);
+      w[1] = pack2<T>(e[2], e[3]);
+      w[2] = pack2<T>(e[4], e[5]);
+      w[3] = pack2<T>(e[6], e[7]);
       pf[s] = __builtin_bit_cast(X8, w);
     }
+    l_i += rs0 + rs1;
 
     // ---- O^T += V^T . P^T
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int dt = 0; dt < DT_; ++dt) {
-        const X4 lo = DT<T>::ds_read_tr(vb + v_rd + ((2 * s + 0) * DT_ + dt) * 512);
-        const X4 hi = DT<T>::ds_read_tr(vb + v_rd + ((2 * s + 1) * DT_ + dt) * 512);
-        X8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-        oacc[dt] = DT<T>::mfma32(vf, pf[s], oacc[dt]);
-      }
-    }
+      for (int dt = 0; dt < DT_; ++dt) oacc[dt] = DT<T>::mfma32(vfr[s][dt], pf[s], oacc[dt]);
   };
 
   for (int t = 0; t < n_tiles; ++t) {
@@ -335,7 +368,7 @@ __global__ __launch_bounds__(256) void fa3_fwd_kernel(const FaDev p) {
       else process_tile(t, std::false_type{});
     }
 
-    if (more) stage_write(cur ^ 1);
+    if (more) stage_write(cur ^ 1, t + 1);
     __syncthreads();
   }
 
