@@ -43,6 +43,7 @@ extern "C" int mio_fa3_fwd(const mio_fa3_fwd_params_t* a, void* stream) {
   p.B = a->B; p.Sq = a->Sq; p.Sk = a->Sk; p.H = a->H; p.Hkv = a->Hkv; p.D = a->D;
   p.carry_in = a->carry_in; p.q_offset = a->q_offset; p.k_offset = a->k_offset;
   p.nqblk = (a->Sq + FA_BM - 1) / FA_BM;
+  p.qgrid = p.nqblk;
   p.xcd_remap = ((a->B * a->H) % 8 == 0) ? 1 : 0;
   p.scale_log2e = a->softmax_scale * FA_LOG2E;
 

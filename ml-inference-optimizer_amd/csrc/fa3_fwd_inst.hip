@@ -1,5 +1,7 @@
 // One translation unit per (dtype, padded head dim): compiled with -DFA_TYPE_ID={0,1} -DFA_D={64,96,128}.
-#include "fa3_fwd_kernel.h"
+#include <cstdlib>
+
+#include "fa3_fwd2_kernel.h"
 
 #if FA_TYPE_ID == 0
 using FaT = __bf16;
@@ -24,8 +26,45 @@ static int launch_one(const FaDev& p, hipStream_t stream) {
   return 0;
 }
 
+// second structure (one wave per SIMD, 64 query rows per wave): no user mask, D % 32 == 0 instantiations
+template <bool CAUSAL>
+static int launch_two(FaDev p, hipStream_t stream) {
+  p.nqblk = (p.Sq + FA2_BM - 1) / FA2_BM;
+  // causal: a workgroup takes query blocks i and nqblk-1-i back to back -> every workgroup does the same work
+  p.qgrid = CAUSAL ? (p.nqblk + 1) / 2 : p.nqblk;
+  if (const char* e = std::getenv("MIO_FA_ORDER")) p.xcd_remap |= std::atoi(e);  // tuning aid: 2 = light-first, 4 = block-major
+  const int grid = p.qgrid * p.B * p.H;
+  const size_t smem = FaSmem<FA_D>::TOTAL;
+  auto kern = fa3_fwd2_kernel<FaT, FA_D, CAUSAL>;
+  static bool attr_set = false;
+  if (!attr_set && smem > 48 * 1024) {
+    hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (ea != hipSuccess) return mio_fail(std::string("fa3_fwd2: hipFuncSetAttribute: ") + hipGetErrorString(ea));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("fa3_fwd2 launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+static int fa_impl() {  // MIO_FA_IMPL=1 selects the first structure (two waves per SIMD) for A/B runs
+  static const int v = [] {
+    const char* e = std::getenv("MIO_FA_IMPL");
+    return e ? std::atoi(e) : 0;
+  }();
+  return v;
+}
+
 template <>
 int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t stream) {
+  // Structure choice (measured on MI355X, B8 S4096 H16, random data): the one-wave-per-SIMD / 64-rows-per-wave
+  // kernel wins at head_dim > 64 (D128 causal 754 vs 555 TFLOP/s, D80 590 vs 407) and for non-causal D64; the
+  // two-waves-per-SIMD kernel stays ahead for causal D64 inside the model (0.48 vs 0.52 ms per layer).
+  // MIO_FA_IMPL=1 / 2 forces one of them for A/B runs.
+  const bool two = (fa_impl() == 2) || (fa_impl() != 1 && (FA_D > 64 || !causal));
+  if (mask_kind == MIO_MASK_NONE && two && p.Sq > 128)
+    return causal ? launch_two<true>(p, stream) : launch_two<false>(p, stream);
   if (causal) {
     if (mask_kind == MIO_MASK_NONE) return launch_one<true, 0>(p, stream);
     if (mask_kind == MIO_MASK_KEEP_U8) return launch_one<true, 1>(p, stream);

@@ -39,6 +39,7 @@ struct FaDev {
   int B, Sq, Sk, H, Hkv, D;
   int carry_in, q_offset, k_offset;
   int nqblk, xcd_remap;
+  int qgrid;  // workgroups per (batch, head): nqblk, or ceil(nqblk/2) when causal blocks are paired (fa3_fwd2)
   float scale_log2e;  // softmax_scale * log2(e)
 };
 
