@@ -108,6 +108,8 @@ __device__ __forceinline__ void fa2_for(F&& f) {
   }
 }
 
+// (Forcing two waves per SIMD at D = 64 -- 192 VGPRs + 64 accumulator registers would fit 256 -- makes hipcc split
+// the file 128/128 and spill 86 VGPRs; left at one wave per SIMD.)
 template <typename T, int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void fa3_fwd2_kernel(const FaDev p) {
   using X8 = typename DT<T>::x8;
