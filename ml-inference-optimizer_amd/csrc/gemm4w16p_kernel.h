@@ -1,0 +1,315 @@
+// Persistent form of gemm4w16_kernel with an OVERLAPPED epilogue (no residual operand).
+//
+// Measured anatomy of gemm4w16_kernel at K = 1024 (tools/gemm_stamps.py): prologue 3.0k, main loop 40k, epilogue
+// 11.5k cycles, and the epilogue is HBM-write bound because all 256 CUs finish a tile together (32 MiB of output
+// in ~7 us while every matrix pipe idles).  Here a workgroup walks its tiles in a loop and the stores of tile i
+// trickle out during tile i+1:
+//   * end of a tile: the 256 accumulator registers are read out, bias + activation applied, packed to 16 bits,
+//     row-pair exchanged (v_permlane16_swap) into 32 x 16-byte chunks per lane held in VGPRs (four 32-dword
+//     register arrays ob0..ob3, one per dword of a chunk), and the accumulators are re-zeroed;
+//   * next tile: every K-tile issues SPK (1, 2 or 4) buffer_store_dwordx4 of the previous tile from its first
+//     micro-steps, chunk index = kt*SPK + s read with VGPR-relative addressing (the index is wave-uniform).  Row /
+//     column edges and "all chunks already sent" are handled by the buffer range check: such a lane gets an
+//     out-of-range offset and its store is dropped -- no branches inside the MFMA stream.  Spreading the stores
+//     over the whole tile matters: vmcnt retires in order, so a burst of stores in front of the prefetch loads
+//     stalls the K loop on HBM write bandwidth (first version of this kernel: 32 stores in two K-tiles, no gain);
+//   * vmcnt counts stores too, but stores are NOT retired in order with loads (a dropped or fast store leaves the
+//     counter early; a first version that allowed "8 loads + the stores issued since" in flight read K-tiles that
+//     had not landed).  The counted wait therefore stays vmcnt(8): with at most 8 operations of any kind in
+//     flight, the loads still in flight are a suffix of at most 8 loads = the K-tile after the one being
+//     retired.  Stores are issued from micro-steps 12..15, right after the 8 prefetch loads of the K-tile, so by
+//     the next wait (8 micro-steps later) they have normally been acknowledged and the wait does not see them.
+//   * the next tile's first three K-tiles are requested BEFORE the read-out (the LDS stages are free once every
+//     wave has left the K loop), so their latency hides behind the ~4k cycles of accumulator read-out; the bias
+//     row is fetched just before them and first touched right after them, so the compiler's wait is a counted
+//     vmcnt(24) and not a vmcnt(0) that would drain the prefetch.
+// Everything else (tile shape, LDS stages and swizzle, buffer_load-to-LDS prefetch, asm-owned accumulators,
+// micro-step order) is gemm4w16_kernel's.  Requires K % 32 == 0 and SPK * (K / 32) >= 32; no residual operand.
+#pragma once
+#include <type_traits>
+
+#include "gemm4w16_kernel.h"
+
+typedef __attribute__((ext_vector_type(32))) uint32_t u32x32_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+template <typename T, int ACT, int SPK, bool STAMP = false>
+__global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
+  using X8 = typename DT<T>::x8;
+  using X4 = typename DT<T>::x4;
+  static_assert(ACT != MIO_ACT_SWIGLU, "dual-B GEMM uses gemm_bias_act_kernel");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int nk = p.K / G6_BK;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int prow = lane >> 2, pcs = lane & 3;
+
+  // fragment read offsets (tile independent)
+  const int co = (g ^ g6_swz(c16)) * 16;
+  const int xbase = (wr * 128 + c16) * 64 + co;
+  const int wbase = G6_XT + (wc * 128 + c16) * 64 + co;
+
+  {  // zero the accumulator file once; afterwards every read-out re-zeroes what it read
+    auto zero_all = [&](auto self, auto K) {
+      constexpr int k = decltype(K)::value;
+      G6AccIO<k>::zero();
+      if constexpr (k + 1 < 64) self(self, std::integral_constant<int, k + 1>{});
+    };
+    zero_all(zero_all, std::integral_constant<int, 0>{});
+  }
+
+  // pending output of the previous tile: 32 chunks of 16 bytes per lane (dword c of chunk j = obc[j]) + where they go
+  u32x32_t ob0, ob1, ob2, ob3;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) ob0[j] = ob1[j] = ob2[j] = ob3[j] = 0u;
+  __amdgpu_buffer_rsrc_t yrs_prev = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0, 0x00020000);
+  // after the exchange a lane holds row (2*mtp + (g&1))*16 + c16 of the wave tile, columns 8*(g>>1) .. +7 of
+  // 16-column tile nt: byte offset of chunk (mtp, nt) = yoff0 + mtp * 64*ldy + nt * 32
+  const int yrow0 = wr * 128 + (g & 1) * 16 + c16;
+  const int yoff0 = (yrow0 * (int)p.ldy + wc * 128 + 8 * (g >> 1)) * 2;
+  const int ystep = 64 * (int)p.ldy;
+  int nchunks_prev = 0;    // 32 once a tile is pending (wave-uniform)
+  bool full_prev = false;  // previous tile lies completely inside M x N: no per-lane masks (wave-uniform)
+  int mrem_prev = 0;       // rows of the previous tile inside M
+  int nvalid_prev = 0;     // chunks nt < nvalid_prev are inside N (per lane)
+
+  X8 fx[2][8];
+  X8 fw[2];
+
+  // ---- operand addressing of the tile being computed / prefetched
+  int xvo[4], wvo[4];
+  __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t wrs = xrs;
+  int64_t m0 = 0;
+  int n0 = 0, nrem = 0;
+  int64_t mrem = 0;
+  auto setup = [&](int tile) {
+    int tm, tn;
+    gemm_tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
+    m0 = (int64_t)tm * 256;
+    n0 = tn * 256;
+    mrem = p.M - m0;
+    nrem = p.N - n0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 16 + prow;
+      const int kch = pcs ^ g6_swz(row);
+      const int xr = (row < mrem) ? row : (int)(mrem - 1);
+      const int wrw = (row < nrem) ? row : (nrem - 1);
+      xvo[i] = xr * (int)p.ldx * 2 + 16 * kch;
+      wvo[i] = wrw * (int)p.ldw * 2 + 16 * kch;
+    }
+    xrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.x + m0 * p.ldx), 0, 0x7fffffff, 0x00020000);
+    wrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.w + (int64_t)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  };
+
+#define IC(N) std::integral_constant<int, N>{}
+  auto issue_one = [&](int kt, auto I, auto WHICH) {
+    constexpr int i = decltype(I)::value, which = decltype(WHICH)::value;
+    const int kte = kt < nk ? kt : nk - 1;
+    char* dst = smem + (kt & (G6_STAGES - 1)) * G6_BUF + which * G6_XT + (wave * 4 + i) * 1024;
+    const int koff = kte * (G6_BK * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? wrs : xrs, (MIO_LDS void*)dst, 16, which ? wvo[i] : xvo[i],
+                                             koff, 0, 0);
+  };
+  // K-tiles 0, 1, 2 of the current `setup` in flight (24 loads per lane)
+  auto issue_prologue = [&]() {
+#define G6P_ISSUE_TILE(KT)                                                                                  \
+  issue_one(KT, IC(0), IC(0)); issue_one(KT, IC(0), IC(1)); issue_one(KT, IC(1), IC(0)); issue_one(KT, IC(1), IC(1)); \
+  issue_one(KT, IC(2), IC(0)); issue_one(KT, IC(2), IC(1)); issue_one(KT, IC(3), IC(0)); issue_one(KT, IC(3), IC(1));
+    G6P_ISSUE_TILE(0)
+    G6P_ISSUE_TILE(1)
+    G6P_ISSUE_TILE(2)
+#undef G6P_ISSUE_TILE
+  };
+  auto read_x = [&](const char* buf, auto RB, auto MT) {
+    constexpr int rb = decltype(RB)::value, mt = decltype(MT)::value;
+    fx[rb][mt] = __builtin_bit_cast(X8, *(const u32x4_t*)(buf + xbase + mt * 16 * 64));
+  };
+  auto read_w = [&](const char* buf, auto NT) {
+    constexpr int nt = decltype(NT)::value;
+    fw[nt & 1] = __builtin_bit_cast(X8, *(const u32x4_t*)(buf + wbase + nt * 16 * 64));
+  };
+  auto mfma4 = [&](auto RB, auto J) {
+    constexpr int rb = decltype(RB)::value, j = decltype(J)::value;
+    constexpr int nt = j / 2, mt0 = (j % 2) * 4;
+    G6Acc<T, nt * 8 + mt0 + 0>::mfma(fw[nt & 1], fx[rb][mt0 + 0]);
+    G6Acc<T, nt * 8 + mt0 + 1>::mfma(fw[nt & 1], fx[rb][mt0 + 1]);
+    G6Acc<T, nt * 8 + mt0 + 2>::mfma(fw[nt & 1], fx[rb][mt0 + 2]);
+    G6Acc<T, nt * 8 + mt0 + 3>::mfma(fw[nt & 1], fx[rb][mt0 + 3]);
+  };
+  // store chunk `chunk` (wave-uniform; = mtp*8 + nt) of the previous tile; scalar branches only
+  auto store_dyn = [&](int chunk) {
+    if (chunk < nchunks_prev) {
+      const int mtp = chunk >> 3, nt = chunk & 7;
+      int off = yoff0 + mtp * ystep;
+      if (!full_prev) {
+        const bool ok = (nt < nvalid_prev) && (yrow0 + 32 * mtp < mrem_prev);
+        off = ok ? off : 0x7fffffff;  // out of range: dropped by the buffer range check
+      }
+      const u32x4_t d = {ob0[chunk], ob1[chunk], ob2[chunk], ob3[chunk]};
+      __builtin_amdgcn_raw_buffer_store_b128(d, yrs_prev, off, nt * 32, 0);
+    }
+  };
+  // One K-tile (see gemm4w16_kernel) + SPK stores of the previous tile from micro-steps 12..12+SPK-1.
+  auto ktile = [&](auto RBv, int kt) {
+    using RB = decltype(RBv);
+    using NRB = std::integral_constant<int, RB::value ^ 1>;
+    const char* buf = smem + (kt & (G6_STAGES - 1)) * G6_BUF;
+    const char* nbuf = smem + ((kt + 1) & (G6_STAGES - 1)) * G6_BUF;
+#define G6P_STEP(J)                                                                        \
+    mfma4(RB{}, IC(J));                                                                    \
+    if constexpr ((J) % 2 == 0 && (J) / 2 + 1 < 8) read_w(buf, IC((J) / 2 + 1));          \
+    if constexpr ((J) >= 12 && (J) - 12 < SPK) store_dyn(kt * SPK + (J) - 12);
+    G6P_STEP(0) __builtin_amdgcn_sched_barrier(0);
+    G6P_STEP(1) __builtin_amdgcn_sched_barrier(0);
+    G6P_STEP(2) __builtin_amdgcn_sched_barrier(0);
+    G6P_STEP(3) __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#define G6P_STEP_B(J, P)                                                                   \
+    G6P_STEP(J)                                                                            \
+    if constexpr ((P) < 8) {                                                               \
+      issue_one(kt + 3, IC((P) / 2), IC((P) % 2));                                         \
+      read_x(nbuf, NRB{}, IC((P) < 8 ? (P) : 0));                                          \
+    }                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+    G6P_STEP_B(4, 0) G6P_STEP_B(5, 1) G6P_STEP_B(6, 2) G6P_STEP_B(7, 3) G6P_STEP_B(8, 4) G6P_STEP_B(9, 5)
+    G6P_STEP_B(10, 6) G6P_STEP_B(11, 7) G6P_STEP_B(12, 8) G6P_STEP_B(13, 8)
+    G6P_STEP(14)
+    read_w(nbuf, IC(0));
+    __builtin_amdgcn_sched_barrier(0);
+    G6P_STEP(15) __builtin_amdgcn_sched_barrier(0);
+#undef G6P_STEP_B
+#undef G6P_STEP
+  };
+
+  int tile = blockIdx.x;  // the launcher keeps gridDim.x <= ntiles
+  setup(tile);
+  issue_prologue();
+  for (;;) {
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, sr0 = 0;
+    if constexpr (STAMP) {
+      st0 = __builtin_amdgcn_s_memtime();
+      sr0 = __builtin_amdgcn_s_memrealtime();
+    }
+    // K-tile 0 has landed (at most K-tiles 1 and 2 = 16 loads still in flight) for every wave
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) fx[0][t] = __builtin_bit_cast(X8, *(const u32x4_t*)(smem + xbase + t * 16 * 64));
+    fw[0] = __builtin_bit_cast(X8, *(const u32x4_t*)(smem + wbase));
+    __builtin_amdgcn_sched_barrier(0);
+
+    if constexpr (STAMP) st1 = __builtin_amdgcn_s_memtime();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      ktile(IC(0), kt);
+      ktile(IC(1), kt + 1);
+    }
+    if (kt < nk) ktile(IC(0), kt);
+    if constexpr (STAMP) st2 = __builtin_amdgcn_s_memtime();
+    // every wave is done with the LDS stages of this tile before anyone prefetches the next tile into them
+    __builtin_amdgcn_s_barrier();
+
+    // ---- this tile's output coordinates and bias row, then the next tile's prologue, then the read-out
+    const int64_t om0 = m0;
+    const int on0 = n0, onrem = nrem;
+    const int omrem = mrem < 256 ? (int)mrem : 256;
+    // Plain loads: the compiler's own wait-count insertion then counts the 24 prologue loads issued after them
+    // (vmcnt(24) at the dummy uses below) instead of draining everything at the first real use.
+    u32x2_t bq[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) bq[nt] = (u32x2_t){0u, 0u};
+    if (p.bias != nullptr) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const int n = on0 + wc * 128 + nt * 16 + 4 * g;
+        const int nc = (n < p.N) ? n : (p.N - 4);
+        bq[nt] = *(const u32x2_t*)((const T*)p.bias + nc);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int next = tile + (int)gridDim.x;
+    const bool has_next = next < ntiles;
+    if (has_next) {
+      setup(next);
+      issue_prologue();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) asm volatile("" ::"v"(bq[nt]));
+    }
+
+    // ---- read-out: accumulators -> bias/activation -> 16-bit -> row-pair exchange -> ob0..3; accumulators := 0
+    // (the last MFMAs must have retired before the accumulator file is read: no interlock for asm readers)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    {
+      auto pair = [&](auto MTP) {
+        constexpr int mtp = decltype(MTP)::value, mt = 2 * mtp;
+        auto col = [&](auto NT) {
+          constexpr int nt = decltype(NT)::value;
+          const X4 bv = __builtin_bit_cast(X4, bq[nt]);
+          const f32x4_t a = G6AccIO<nt * 8 + mt>::read();
+          const f32x4_t b = G6AccIO<nt * 8 + mt + 1>::read();
+          G6AccIO<nt * 8 + mt>::zero();
+          G6AccIO<nt * 8 + mt + 1>::zero();
+          float va[4], vb[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            va[e] = gemm_act<ACT>(a[e] + (float)bv[e]);
+            vb[e] = gemm_act<ACT>(b[e] + (float)bv[e]);
+          }
+          const auto s0 = __builtin_amdgcn_permlane16_swap(pack2<T>(va[0], va[1]), pack2<T>(vb[0], vb[1]), false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(pack2<T>(va[2], va[3]), pack2<T>(vb[2], vb[3]), false, false);
+          ob0[mtp * 8 + nt] = s0[0];
+          ob1[mtp * 8 + nt] = s1[0];
+          ob2[mtp * 8 + nt] = s0[1];
+          ob3[mtp * 8 + nt] = s1[1];
+        };
+        col(IC(0)); col(IC(1)); col(IC(2)); col(IC(3)); col(IC(4)); col(IC(5)); col(IC(6)); col(IC(7));
+      };
+      pair(IC(0)); pair(IC(1)); pair(IC(2)); pair(IC(3));
+    }
+    if constexpr (STAMP) {  // per (tile, wave): tile start, loop start, loop end, read-out end; 100 MHz start / end
+      const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+      const unsigned long long sr1 = __builtin_amdgcn_s_memrealtime();
+      if (lane == 0 && p.dbg != nullptr) {
+        unsigned long long* d = p.dbg + ((size_t)tile * 4 + wave) * 8;
+        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = sr0; d[5] = sr1; d[6] = blockIdx.x; d[7] = 0;
+      }
+    }
+    // where this tile's chunks go
+    yrs_prev = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.y + om0 * p.ldy + on0), 0, 0x7fffffff, 0x00020000);
+    nchunks_prev = 32;
+    full_prev = (omrem == 256) && (onrem >= 256);
+    mrem_prev = omrem;
+    {
+      const int c0 = wc * 128 + 8 * (g >> 1);  // first column of this lane's chunk in tile nt = 0
+      int nv = (onrem - c0 + 15) / 16;
+      nvalid_prev = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
+    }
+    if (!has_next) break;
+    tile = next;
+  }
+
+  // ---- flush the last tile's output
+  {
+    auto flush = [&](auto self, auto Jc) {
+      constexpr int j = decltype(Jc)::value;
+      constexpr int mtp = j / 8, nt = j % 8;
+      const bool ok = (nt < nvalid_prev) && (yrow0 + 32 * mtp < mrem_prev);
+      const int off = ok ? yoff0 + mtp * ystep : 0x7fffffff;
+      const u32x4_t d = {ob0[j], ob1[j], ob2[j], ob3[j]};
+      __builtin_amdgcn_raw_buffer_store_b128(d, yrs_prev, off, nt * 32, 0);
+      if constexpr (j + 1 < 32) self(self, IC(j + 1));
+    };
+    flush(flush, IC(0));
+  }
+#undef IC
+}

@@ -4,6 +4,7 @@
 
 #include "gemm2x_kernel.h"
 #include "gemm4w16_kernel.h"
+#include "gemm4w16p_kernel.h"
 #include "gemm4w_kernel.h"
 #include "gemm8p_kernel.h"
 
@@ -124,6 +125,40 @@ static int launch_4w16(GemmDev p, hipStream_t stream) {
   return 0;
 }
 
+// persistent variant with the overlapped epilogue (no residual operand, K >= 128)
+template <int ACT, int SPK = 0>
+static int launch_4w16p(GemmDev p, hipStream_t stream) {
+  if constexpr (SPK == 0) {  // stores per K-tile so that all 32 chunks of a tile leave during the next one
+    const int nk = p.K / 32;
+    if (nk >= 32) return launch_4w16p<ACT, 1>(p, stream);
+    if (nk >= 16) return launch_4w16p<ACT, 2>(p, stream);
+    return launch_4w16p<ACT, 4>(p, stream);
+  }
+  p.tiles_m = (int)((p.M + 255) / 256);
+  p.tiles_n = (p.N + 255) / 256;
+  constexpr bool CAN_STAMP = (ACT == MIO_ACT_NONE && SPK == 1);
+  auto kern = gemm4w16p_kernel<GT, ACT, (SPK == 0 ? 1 : SPK)>;
+  if constexpr (CAN_STAMP) {
+    if (p.dbg != nullptr) kern = gemm4w16p_kernel<GT, ACT, 1, true>;
+  }
+  static bool attr_set = false;
+  static int ncu = 256;
+  if (!attr_set || p.dbg != nullptr) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G6_SMEM);
+    if (e != hipSuccess) return mio_fail(std::string("gemm4w16p: hipFuncSetAttribute: ") + hipGetErrorString(e));
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      ncu = n & ~7;  // whole XCD groups, so tile % 8 keeps naming the XCD
+    attr_set = true;
+  }
+  const int tiles = p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL(kern, dim3(tiles < ncu ? tiles : ncu), dim3(256), G6_SMEM, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("gemm4w16p launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
 template <int ACT>
 static int launch_2x(GemmDev p, hipStream_t stream) {
   p.tiles_m = (int)((p.M + 255) / 256);
@@ -150,6 +185,8 @@ static int gemm_impl() {
     if (std::string(e) == "8p") return 2;
     if (std::string(e) == "4w") return 3;
     if (std::string(e) == "2x") return 4;
+    if (std::string(e) == "4wp") return 5;
+    if (std::string(e) == "4w16") return 6;
     return 0;
   }();
   return v;
@@ -173,6 +210,9 @@ static int launch_act(const GemmDev& p, hipStream_t stream) {
       const bool fits = (p.K % 32 == 0) && (p.ldx * 512 < (int64_t)0x7fffffff) && (p.ldw * 512 < (int64_t)0x7fffffff);
       if (!fits) return launch_cfg<256, 256, 2, 4, ACT>(p, stream);
       if (gemm_impl() == 4) return launch_2x<ACT>(p, stream);
+      // no residual: persistent kernel with the overlapped epilogue (MIO_GEMM_IMPL=4w16 keeps the one-tile kernel)
+      if (gemm_impl() != 6 && p.res == nullptr && p.K >= 256 && p.ldy * 512 < (int64_t)0x7fffffff)
+        return launch_4w16p<ACT>(p, stream);
       return launch_4w16<ACT>(p, stream);
     }
     return launch_cfg<128, 128, 2, 2, ACT>(p, stream);

@@ -215,6 +215,51 @@ def test_gemm_edges_and_residual(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,act,res", [
+    (4096 + 37, 4096 + 8, 1024, "none", False),   # persistent kernel, 1 store / K-tile, ragged M and N, 289 tiles
+    (8192, 2304 + 24, 256, "gelu", False),        # persistent, 4 stores / K-tile, 320 tiles
+    (5000, 3584, 544, "silu", False),             # persistent, 2 stores / K-tile, odd number of K-tiles
+    (4352, 4096, 288, "none", True),              # residual epilogue -> one-tile-per-workgroup 256x256 kernel
+    (4352 + 3, 4096, 264, "relu", True),          # K % 32 != 0 -> generic 256x256 kernel
+])
+def test_gemm_big_tiles(dtype, M, N, K, act, res):
+    """The 256x256-tile kernels only run when a launch has >= 256 such tiles (mio gemm_inst.hip launch_act): sizes
+    the numpy oracle cannot finish in seconds, so the checker here is a CPU fp32 matmul of the same 16-bit inputs
+    + the oracle's activation (oracle/mlp.py), which is the reference's F.linear + activation
+    (kernels/mlp/fused_mlp.py:159-176)."""
+    ops = _ops()
+    torch.manual_seed(5)
+    x = torch.randn(M, K).to(dtype)
+    w = (torch.randn(N, K) * 0.05).to(dtype)
+    b = torch.randn(N).to(dtype)
+    r = torch.randn(M, N).to(dtype) if res else None
+    y = ops.gemm_bias_act(x.to(DEV), w.to(DEV), b.to(DEV), act, residual=None if r is None else r.to(DEV))
+    from oracle.mlp import gelu_tanh
+    z = (x.float() @ w.float().T).double() + b.double()
+    z = {"none": lambda t: t, "gelu": gelu_tanh, "relu": torch.relu, "silu": torch.nn.functional.silu}[act](z)
+    if r is not None:
+        z = z + r.double()
+    _cmp(y, z, dtype, f"gemm {M}x{N}x{K} {act} res={res}")
+
+
+def test_gemm_big_tiles_exact():
+    """Bit-exact integer case for the persistent kernel: x, w in {-1, 0, 1}, K = 256 keeps every dot product an
+    integer of magnitude <= 256 (exact in bf16); every tile of every workgroup must match integer arithmetic, and
+    rows / columns past the ragged edge must stay untouched."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 4096 + 250, 4096 + 16, 256
+    x = torch.randint(-1, 2, (M, K), generator=g)
+    w = torch.randint(-1, 2, (N, K), generator=g)
+    out = torch.full((M + 2, N + 8), 7.0, dtype=torch.bfloat16, device=DEV)  # guard rows / columns around the view
+    view = out[:M, :N]
+    ops.gemm_bias_act(x.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV), None, out=view)
+    ref = (x.double() @ w.double().T)
+    assert torch.equal(view.double().cpu(), ref)
+    assert bool((out[M:, :] == 7).all()) and bool((out[:, N:] == 7).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_layernorm(golden_dir, dtype):
     ops = _ops()
     g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "layernorm.npz")).items()}

@@ -13,11 +13,23 @@ sys.path.insert(0, os.path.join(ROOT, "ml-inference-optimizer_amd"))
 from mio import ops  # noqa: E402
 
 
-def timeit(fn, iters=20, warmup=3):
+def timeit(fn, iters=20, warmup=3, sustain_s=0.3):
+    """Seconds per call, HIP events.  The chip only settles at its sustained clock / power point after a few
+    hundred ms of back-to-back work (tools/gemm_power.py: a 20-launch burst measured 217 us for a GEMM that runs
+    191 us sustained), so warm up for `sustain_s` of queued launches and time at least as long."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    fn()
+    e.record()
+    torch.cuda.synchronize()
+    est = max(s.elapsed_time(e) * 1e-3, 1e-6)
+    n = int(sustain_s / est)
+    for _ in range(n):
+        fn()
+    iters = max(iters, n)
     s.record()
     for _ in range(iters):
         fn()
