@@ -19,12 +19,13 @@
 //     flight, the loads still in flight are a suffix of at most 8 loads = the K-tile after the one being
 //     retired.  Stores are issued from micro-steps 12..15, right after the 8 prefetch loads of the K-tile, so by
 //     the next wait (8 micro-steps later) they have normally been acknowledged and the wait does not see them.
-//   * the next tile's first three K-tiles are requested BEFORE the read-out (the LDS stages are free once every
-//     wave has left the K loop), so their latency hides behind the ~4k cycles of accumulator read-out; the bias
-//     row is fetched just before them and first touched right after them, so the compiler's wait is a counted
-//     vmcnt(24) and not a vmcnt(0) that would drain the prefetch.
+//   * the load stream never drains between tiles: the last three K-tiles of a tile prefetch K-tiles 0..2 of the
+//     workgroup's NEXT tile (the LDS stage index runs on across tiles), so the only per-tile bubble left is the
+//     ~4k-cycle accumulator read-out, during which those loads land.  The bias row of the tile is fetched before
+//     those three K-tiles.
 // Everything else (tile shape, LDS stages and swizzle, buffer_load-to-LDS prefetch, asm-owned accumulators,
-// micro-step order) is gemm4w16_kernel's.  Requires K % 32 == 0 and SPK * (K / 32) >= 32; no residual operand.
+// micro-step order) is gemm4w16_kernel's.  Requires K % 64 == 0 (an even number of K-tiles keeps the fragment
+// double-buffer parity across tiles) and SPK * (K / 32) >= 32; no residual operand.
 #pragma once
 #include <type_traits>
 
@@ -108,19 +109,21 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
   };
 
 #define IC(N) std::integral_constant<int, N>{}
-  auto issue_one = [&](int kt, auto I, auto WHICH) {
+  int sbase = 0;  // LDS stage of the current tile's K-tile 0 (the stage index runs on across tiles)
+  // request piece (i, which) of K-tile `kl` of the tile `setup` describes into stage (sbase + ks) & 3
+  auto issue_one = [&](int ks, int kl, auto I, auto WHICH) {
     constexpr int i = decltype(I)::value, which = decltype(WHICH)::value;
-    const int kte = kt < nk ? kt : nk - 1;
-    char* dst = smem + (kt & (G6_STAGES - 1)) * G6_BUF + which * G6_XT + (wave * 4 + i) * 1024;
-    const int koff = kte * (G6_BK * 2);
+    char* dst = smem + ((sbase + ks) & (G6_STAGES - 1)) * G6_BUF + which * G6_XT + (wave * 4 + i) * 1024;
+    const int koff = kl * (G6_BK * 2);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? wrs : xrs, (MIO_LDS void*)dst, 16, which ? wvo[i] : xvo[i],
                                              koff, 0, 0);
   };
   // K-tiles 0, 1, 2 of the current `setup` in flight (24 loads per lane)
   auto issue_prologue = [&]() {
 #define G6P_ISSUE_TILE(KT)                                                                                  \
-  issue_one(KT, IC(0), IC(0)); issue_one(KT, IC(0), IC(1)); issue_one(KT, IC(1), IC(0)); issue_one(KT, IC(1), IC(1)); \
-  issue_one(KT, IC(2), IC(0)); issue_one(KT, IC(2), IC(1)); issue_one(KT, IC(3), IC(0)); issue_one(KT, IC(3), IC(1));
+  issue_one(KT, KT, IC(0), IC(0)); issue_one(KT, KT, IC(0), IC(1)); issue_one(KT, KT, IC(1), IC(0));       \
+  issue_one(KT, KT, IC(1), IC(1)); issue_one(KT, KT, IC(2), IC(0)); issue_one(KT, KT, IC(2), IC(1));       \
+  issue_one(KT, KT, IC(3), IC(0)); issue_one(KT, KT, IC(3), IC(1));
     G6P_ISSUE_TILE(0)
     G6P_ISSUE_TILE(1)
     G6P_ISSUE_TILE(2)
@@ -142,29 +145,45 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
     G6Acc<T, nt * 8 + mt0 + 2>::mfma(fw[nt & 1], fx[rb][mt0 + 2]);
     G6Acc<T, nt * 8 + mt0 + 3>::mfma(fw[nt & 1], fx[rb][mt0 + 3]);
   };
-  // store chunk `chunk` (wave-uniform; = mtp*8 + nt) of the previous tile; scalar branches only
-  auto store_dyn = [&](int chunk) {
+  // store chunk `chunk` (wave-uniform; = mtp*8 + nt) of the previous tile; scalar branches only.  Three phases so
+  // that each fits the shadow of one 4-MFMA micro-step: address, VGPR-relative read of the chunk, store.
+  int st_off = 0;
+  u32x4_t st_d = {0u, 0u, 0u, 0u};
+  auto store_phase = [&](int chunk, auto PH) {
+    constexpr int ph = decltype(PH)::value;
     if (chunk < nchunks_prev) {
       const int mtp = chunk >> 3, nt = chunk & 7;
-      int off = yoff0 + mtp * ystep;
-      if (!full_prev) {
-        const bool ok = (nt < nvalid_prev) && (yrow0 + 32 * mtp < mrem_prev);
-        off = ok ? off : 0x7fffffff;  // out of range: dropped by the buffer range check
+      if constexpr (ph == 0 || ph == 3) {
+        int off = yoff0 + mtp * ystep;
+        if (!full_prev) {
+          const bool ok = (nt < nvalid_prev) && (yrow0 + 32 * mtp < mrem_prev);
+          off = ok ? off : 0x7fffffff;  // out of range: dropped by the buffer range check
+        }
+        st_off = off;
       }
-      const u32x4_t d = {ob0[chunk], ob1[chunk], ob2[chunk], ob3[chunk]};
-      __builtin_amdgcn_raw_buffer_store_b128(d, yrs_prev, off, nt * 32, 0);
+      if constexpr (ph == 1 || ph == 3) st_d = (u32x4_t){ob0[chunk], ob1[chunk], ob2[chunk], ob3[chunk]};
+      if constexpr (ph == 2 || ph == 3) __builtin_amdgcn_raw_buffer_store_b128(st_d, yrs_prev, st_off, nt * 32, 0);
     }
   };
-  // One K-tile (see gemm4w16_kernel) + SPK stores of the previous tile from micro-steps 12..12+SPK-1.
-  auto ktile = [&](auto RBv, int kt) {
+  // One K-tile (see gemm4w16_kernel) + SPK stores of the previous tile (SPK = 1: phases in micro-steps 12, 13, 14;
+  // otherwise one whole store in each of micro-steps 12..12+SPK-1).  TAIL: the K-tile prefetched three ahead lies
+  // past this tile -> K-tile kt+3-nk of the tile `setup` now describes (the next tile, or this one again when the
+  // workgroup has no next tile: harmless, never read).
+  auto ktile = [&](auto RBv, int kt, auto TAILv) {
     using RB = decltype(RBv);
     using NRB = std::integral_constant<int, RB::value ^ 1>;
-    const char* buf = smem + (kt & (G6_STAGES - 1)) * G6_BUF;
-    const char* nbuf = smem + ((kt + 1) & (G6_STAGES - 1)) * G6_BUF;
+    constexpr bool TAIL = decltype(TAILv)::value != 0;
+    const char* buf = smem + ((sbase + kt) & (G6_STAGES - 1)) * G6_BUF;
+    const char* nbuf = smem + ((sbase + kt + 1) & (G6_STAGES - 1)) * G6_BUF;
+    const int kl = TAIL ? kt + 3 - nk : kt + 3;
 #define G6P_STEP(J)                                                                        \
     mfma4(RB{}, IC(J));                                                                    \
     if constexpr ((J) % 2 == 0 && (J) / 2 + 1 < 8) read_w(buf, IC((J) / 2 + 1));          \
-    if constexpr ((J) >= 12 && (J) - 12 < SPK) store_dyn(kt * SPK + (J) - 12);
+    if constexpr (SPK == 1) {                                                              \
+      if constexpr ((J) >= 12 && (J) <= 14) store_phase(kt, IC((J) - 12));                 \
+    } else {                                                                               \
+      if constexpr ((J) >= 12 && (J) - 12 < SPK) store_phase(kt * SPK + (J) - 12, IC(3)); \
+    }
     G6P_STEP(0) __builtin_amdgcn_sched_barrier(0);
     G6P_STEP(1) __builtin_amdgcn_sched_barrier(0);
     G6P_STEP(2) __builtin_amdgcn_sched_barrier(0);
@@ -176,7 +195,7 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
 #define G6P_STEP_B(J, P)                                                                   \
     G6P_STEP(J)                                                                            \
     if constexpr ((P) < 8) {                                                               \
-      issue_one(kt + 3, IC((P) / 2), IC((P) % 2));                                         \
+      issue_one(kt + 3, kl, IC((P) / 2), IC((P) % 2));                                     \
       read_x(nbuf, NRB{}, IC((P) < 8 ? (P) : 0));                                          \
     }                                                                                      \
     __builtin_amdgcn_sched_barrier(0);
@@ -193,37 +212,31 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
   int tile = blockIdx.x;  // the launcher keeps gridDim.x <= ntiles
   setup(tile);
   issue_prologue();
+  // K-tile 0 has landed (at most K-tiles 1 and 2 = 16 loads still in flight) for every wave
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int t = 0; t < 8; ++t) fx[0][t] = __builtin_bit_cast(X8, *(const u32x4_t*)(smem + xbase + t * 16 * 64));
+  fw[0] = __builtin_bit_cast(X8, *(const u32x4_t*)(smem + wbase));
+  __builtin_amdgcn_sched_barrier(0);
   for (;;) {
     unsigned long long st0 = 0, st1 = 0, st2 = 0, sr0 = 0;
     if constexpr (STAMP) {
-      st0 = __builtin_amdgcn_s_memtime();
+      st0 = st1 = __builtin_amdgcn_s_memtime();
       sr0 = __builtin_amdgcn_s_memrealtime();
     }
-    // K-tile 0 has landed (at most K-tiles 1 and 2 = 16 loads still in flight) for every wave
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int t = 0; t < 8; ++t) fx[0][t] = __builtin_bit_cast(X8, *(const u32x4_t*)(smem + xbase + t * 16 * 64));
-    fw[0] = __builtin_bit_cast(X8, *(const u32x4_t*)(smem + wbase));
-    __builtin_amdgcn_sched_barrier(0);
-
-    if constexpr (STAMP) st1 = __builtin_amdgcn_s_memtime();
+    // K-tiles 0 .. nk-4 prefetch inside this tile (nk is even and >= 8)
     int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-      ktile(IC(0), kt);
-      ktile(IC(1), kt + 1);
+    for (; kt < nk - 4; kt += 2) {
+      ktile(IC(0), kt, IC(0));
+      ktile(IC(1), kt + 1, IC(0));
     }
-    if (kt < nk) ktile(IC(0), kt);
-    if constexpr (STAMP) st2 = __builtin_amdgcn_s_memtime();
-    // every wave is done with the LDS stages of this tile before anyone prefetches the next tile into them
-    __builtin_amdgcn_s_barrier();
+    ktile(IC(0), kt, IC(0));  // kt = nk - 4: requests this tile's last K-tile
 
-    // ---- this tile's output coordinates and bias row, then the next tile's prologue, then the read-out
+    // ---- this tile's output coordinates and bias row; from here on `setup` describes the next tile
     const int64_t om0 = m0;
     const int on0 = n0, onrem = nrem;
     const int omrem = mrem < 256 ? (int)mrem : 256;
-    // Plain loads: the compiler's own wait-count insertion then counts the 24 prologue loads issued after them
-    // (vmcnt(24) at the dummy uses below) instead of draining everything at the first real use.
     u32x2_t bq[8];
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) bq[nt] = (u32x2_t){0u, 0u};
@@ -235,16 +248,15 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
         bq[nt] = *(const u32x2_t*)((const T*)p.bias + nc);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
     const int next = tile + (int)gridDim.x;
     const bool has_next = next < ntiles;
-    if (has_next) {
-      setup(next);
-      issue_prologue();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) asm volatile("" ::"v"(bq[nt]));
-    }
+    if (has_next) setup(next);
+    __builtin_amdgcn_sched_barrier(0);
+    ktile(IC(1), kt + 1, IC(1));
+    ktile(IC(0), kt + 2, IC(1));
+    ktile(IC(1), kt + 3, IC(1));
+    sbase = (sbase + nk) & (G6_STAGES - 1);
+    if constexpr (STAMP) st2 = __builtin_amdgcn_s_memtime();
 
     // ---- read-out: accumulators -> bias/activation -> 16-bit -> row-pair exchange -> ob0..3; accumulators := 0
     // (the last MFMAs must have retired before the accumulator file is read: no interlock for asm readers)

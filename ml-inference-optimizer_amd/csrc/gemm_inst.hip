@@ -211,7 +211,7 @@ static int launch_act(const GemmDev& p, hipStream_t stream) {
       if (!fits) return launch_cfg<256, 256, 2, 4, ACT>(p, stream);
       if (gemm_impl() == 4) return launch_2x<ACT>(p, stream);
       // no residual: persistent kernel with the overlapped epilogue (MIO_GEMM_IMPL=4w16 keeps the one-tile kernel)
-      if (gemm_impl() != 6 && p.res == nullptr && p.K >= 256 && p.ldy * 512 < (int64_t)0x7fffffff)
+      if (gemm_impl() != 6 && p.res == nullptr && p.K >= 256 && p.K % 64 == 0 && p.ldy * 512 < (int64_t)0x7fffffff)
         return launch_4w16p<ACT>(p, stream);
       return launch_4w16<ACT>(p, stream);
     }
