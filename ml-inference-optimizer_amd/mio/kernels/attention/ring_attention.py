@@ -1,0 +1,157 @@
+"""Ring-attention modules behind the reference's surface (kernels/attention/ring_attention.py).
+
+Semantics ("A"): exact softmax attention over KV chunks with a running (max, sum, acc) state --
+the reference's Triton kernel `_ring_attention_forward_kernel` and its PyTorch fallback
+(kernels/triton/attention_kernels.py:35-202, 1520-1591), and `RingCrossAttention._ring_cross_attention`
+(ring_attention.py:597-660).  On one GPU that is one launch of the tiled HIP kernel (the KV loop IS the chunk
+loop); across GPUs the same kernel runs once per ring step with the (o_acc, lse) carry
+(mio.parallelism.sequence_parallel.ring_attention).  `RingSelfAttention._ring_self_attention`
+(:349-372) is a different, non-exact recurrence in the reference and is deliberately not reproduced.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..._nn import CastCache, compute_dtype, linear
+
+
+@dataclass
+class RingAttentionConfig:
+    """Mirror of RingAttentionConfig (ring_attention.py:40-89); same fields, same validation errors.
+    `use_triton` is accepted for signature compatibility: the HIP kernel is the only compute path."""
+    world_size: int = 1
+    chunk_size: Optional[int] = None
+    fuse_qkv: bool = True
+    use_flash_attention: bool = False
+    use_triton: bool = True
+    precision: str = "bf16"
+    communication_dtype: torch.dtype = torch.bfloat16
+    normalize_attention_scores: bool = True
+    attention_dropout: float = 0.0
+
+    def __post_init__(self):
+        if self.world_size < 1:
+            raise ValueError(f"world_size must be >= 1, got {self.world_size}")
+        if self.chunk_size is not None and self.chunk_size <= 0:
+            raise ValueError(f"chunk_size must be > 0 if specified, got {self.chunk_size}")
+        if self.precision not in ["fp32", "fp16", "bf16"]:
+            raise ValueError(f"precision must be one of ['fp32', 'fp16', 'bf16'], got {self.precision}")
+        if self.attention_dropout < 0 or self.attention_dropout >= 1:
+            raise ValueError(f"attention_dropout must be in [0, 1), got {self.attention_dropout}")
+        self.compute_dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[self.precision]
+
+
+class RingAttention(nn.Module):
+    """Base class (ring_attention.py:92-166)."""
+
+    def __init__(self, hidden_size: int, num_attention_heads: int, config: RingAttentionConfig):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.num_attention_heads = num_attention_heads
+        self.config = config
+        self.head_dim = hidden_size // num_attention_heads
+        if self.head_dim * num_attention_heads != hidden_size:
+            raise ValueError(
+                f"hidden_size ({hidden_size}) is not divisible by num_attention_heads ({num_attention_heads})")
+        self.scale = 1.0 / math.sqrt(self.head_dim)
+        self._cast = CastCache()
+
+    def get_effective_bytes_per_token(self) -> int:
+        """Bytes of K+V per token held at a time by one rank (:128-149)."""
+        elem = torch.empty((), dtype=self.config.compute_dtype).element_size()
+        return 2 * self.hidden_size * elem
+
+    def calculate_theoretical_memory_savings(self, seq_len: int) -> float:
+        """Score-matrix bytes a dense implementation would hold / bytes of the tiled form (:151-165)."""
+        dense = seq_len * seq_len * self.num_attention_heads
+        tiled = seq_len * self.hidden_size * 2
+        return dense / max(tiled, 1)
+
+    def _check(self, x: torch.Tensor) -> torch.dtype:
+        if x.dim() != 3:
+            raise ValueError(f"Expected 3D input tensor, got shape: {x.shape}")
+        if not x.is_cuda:
+            raise ValueError("HIP kernels require input tensors to be on a CUDA (ROCm) device.")
+        if self.training and self.config.attention_dropout > 0.0:
+            raise NotImplementedError("attention dropout (training) is not supported by the inference kernel")
+        return compute_dtype(self.config.precision, x)
+
+    def _heads(self, t: torch.Tensor) -> torch.Tensor:
+        """[B,S,H*D] -> head-major VIEW [B,H,S,D] (the kernel takes strides; nothing is copied)."""
+        B, S, _ = t.shape
+        return t.view(B, S, self.num_attention_heads, self.head_dim).permute(0, 2, 1, 3)
+
+
+class RingSelfAttention(RingAttention):
+    """Self-attention shell (ring_attention.py:168-410): fused or separate q/k/v projections, `out_proj`."""
+
+    def __init__(self, hidden_size: int, num_attention_heads: int, config: RingAttentionConfig):
+        super().__init__(hidden_size, num_attention_heads, config)
+        if config.fuse_qkv:
+            self.qkv_proj = nn.Linear(hidden_size, 3 * hidden_size, bias=True)
+        else:
+            self.q_proj = nn.Linear(hidden_size, hidden_size, bias=True)
+            self.k_proj = nn.Linear(hidden_size, hidden_size, bias=True)
+            self.v_proj = nn.Linear(hidden_size, hidden_size, bias=True)
+        self.out_proj = nn.Linear(hidden_size, hidden_size, bias=True)
+        self.attention_dropout = nn.Dropout(config.attention_dropout)
+
+    def prepare_attention_inputs(self, hidden_states: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(q, k, v) as [B,H,S,D] views (:237-273).  The 1/sqrt(D) scale is applied inside the kernel, not to q."""
+        dt = self._check(hidden_states)
+        x = hidden_states if hidden_states.dtype == dt else hidden_states.to(dt)
+        B, S, d = x.shape
+        c = self._cast
+        if self.config.fuse_qkv:
+            qkv = linear(x, self.qkv_proj, c, dt).view(B, S, 3, self.num_attention_heads, self.head_dim)
+            q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        else:
+            q = self._heads(linear(x, self.q_proj, c, dt))
+            k = self._heads(linear(x, self.k_proj, c, dt))
+            v = self._heads(linear(x, self.v_proj, c, dt))
+        return q, k, v
+
+    def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """hidden_states [B,S,d]; attention_mask additive, broadcastable to [B,1|H,S,S] (:200-235)."""
+        in_dtype = hidden_states.dtype
+        q, k, v = self.prepare_attention_inputs(hidden_states)
+        dt = q.dtype
+        if attention_mask is not None and attention_mask.dim() == 4 and attention_mask.shape[2] == 1:
+            attention_mask = attention_mask.expand(-1, -1, q.shape[2], -1)  # [B,1,1,S] key mask -> per query row
+        ctx = ops.ring_attention_forward(q, k, v, attention_mask)
+        out = linear(ctx, self.out_proj, self._cast, dt)
+        return out if out.dtype == in_dtype else out.to(in_dtype)
+
+
+class RingCrossAttention(RingAttention):
+    """Cross-attention shell (ring_attention.py:413-669): q from `query_states`, k/v from `key_value_states`."""
+
+    def __init__(self, hidden_size: int, num_attention_heads: int, config: RingAttentionConfig):
+        super().__init__(hidden_size, num_attention_heads, config)
+        self.q_proj = nn.Linear(hidden_size, hidden_size, bias=True)
+        self.k_proj = nn.Linear(hidden_size, hidden_size, bias=True)
+        self.v_proj = nn.Linear(hidden_size, hidden_size, bias=True)
+        self.out_proj = nn.Linear(hidden_size, hidden_size, bias=True)
+        self.attention_dropout = nn.Dropout(config.attention_dropout)
+
+    def forward(self, query_states: torch.Tensor, key_value_states: torch.Tensor,
+                attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """query_states [B,Sq,d], key_value_states [B,Sk,d], additive mask [B,1|H,Sq,Sk] (:442-499)."""
+        in_dtype = query_states.dtype
+        dt = self._check(query_states)
+        self._check(key_value_states)
+        xq = query_states if query_states.dtype == dt else query_states.to(dt)
+        xkv = key_value_states if key_value_states.dtype == dt else key_value_states.to(dt)
+        c = self._cast
+        q = self._heads(linear(xq, self.q_proj, c, dt))
+        k = self._heads(linear(xkv, self.k_proj, c, dt))
+        v = self._heads(linear(xkv, self.v_proj, c, dt))
+        ctx = ops.ring_attention_forward(q, k, v, attention_mask)
+        out = linear(ctx, self.out_proj, c, dt)
+        return out if out.dtype == in_dtype else out.to(in_dtype)

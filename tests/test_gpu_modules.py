@@ -140,3 +140,106 @@ def test_mlp_converter_module_on_gpu():
         ref = oracle.fused_mlp(x.cpu(), sd["mlp.fc1.weight"], sd["mlp.fc1.bias"], sd["mlp.fc2.weight"], sd["mlp.fc2.bias"],
                                oact, sd.get("mlp.fc1_gate.weight"), sd.get("mlp.fc1_gate.bias"))
         assert _rel(y, ref) < 3e-3
+
+
+@pytest.mark.parametrize("fuse_qkv", [True, False])
+def test_ring_attention_modules(fuse_qkv):
+    """RingSelfAttention / RingCrossAttention shells (ring_attention.py:168-669) against the oracle's exact
+    attention on the same projections; additive mask [B,1,Sq,Sk]."""
+    from mio.kernels.attention import RingAttentionConfig, RingCrossAttention, RingSelfAttention
+    torch.manual_seed(3)
+    d, H, B, Sq, Sk = 128, 2, 2, 140, 200
+    dtype = torch.float16
+    cfg = RingAttentionConfig(fuse_qkv=fuse_qkv, precision="fp16")
+    x = torch.randn(B, Sq, d, dtype=dtype)
+    ctx = torch.randn(B, Sk, d, dtype=dtype)
+
+    def heads(t):
+        return t.view(t.shape[0], t.shape[1], H, d // H)
+
+    m = RingSelfAttention(d, H, cfg)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn_like(p) * 0.08)
+    m = m.to(DEV, dtype).eval()
+    sd = {k: v.cpu().double() for k, v in m.state_dict().items()}
+    mask = torch.zeros(B, 1, Sq, Sq)
+    mask[:, :, :, Sq - 17:] = -1e9
+    y = m(x.to(DEV), attention_mask=mask.to(DEV))
+    xf = x.double()
+    if fuse_qkv:
+        qkv = F.linear(xf, sd["qkv_proj.weight"], sd["qkv_proj.bias"]).view(B, Sq, 3, H, d // H)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    else:
+        q, k, v = (heads(F.linear(xf, sd[f"{n}_proj.weight"], sd[f"{n}_proj.bias"])) for n in "qkv")
+    ref = oracle.standard_attention(q, k, v, additive_mask=mask.double()).reshape(B, Sq, d)
+    ref = F.linear(ref, sd["out_proj.weight"], sd["out_proj.bias"])
+    assert _rel(y, ref) < 3e-3
+
+    c = RingCrossAttention(d, H, cfg)
+    with torch.no_grad():
+        for p in c.parameters():
+            p.copy_(torch.randn_like(p) * 0.08)
+    c = c.to(DEV, dtype).eval()
+    sd = {k: v.cpu().double() for k, v in c.state_dict().items()}
+    y = c(x.to(DEV), ctx.to(DEV))
+    q = heads(F.linear(x.double(), sd["q_proj.weight"], sd["q_proj.bias"]))
+    k = heads(F.linear(ctx.double(), sd["k_proj.weight"], sd["k_proj.bias"]))
+    v = heads(F.linear(ctx.double(), sd["v_proj.weight"], sd["v_proj.bias"]))
+    ref = F.linear(oracle.standard_attention(q, k, v).reshape(B, Sq, d), sd["out_proj.weight"], sd["out_proj.bias"])
+    assert _rel(y, ref) < 3e-3
+
+
+def test_fusion_registry_on_gpu():
+    """fusion_registry.fuse_modules output == the unfused torch modules (exact and tanh GELU, ReLU)."""
+    from mio.baseline.inference import fusion_registry
+    torch.manual_seed(4)
+    dtype = torch.float16
+    seq = torch.nn.Sequential(torch.nn.Linear(96, 256), torch.nn.GELU(), torch.nn.Linear(256, 96),
+                              torch.nn.Linear(96, 160), torch.nn.GELU(approximate="tanh"), torch.nn.Linear(160, 96),
+                              torch.nn.Linear(96, 128), torch.nn.ReLU(), torch.nn.Linear(128, 96)).to(DEV, dtype).eval()
+    fused = fusion_registry.fuse_modules(seq).eval()
+    assert [type(m).__name__ for m in fused] == ["FusedMLP", "FusedMLPGeluTanh", "FusedMLPReLU"]
+    x = torch.randn(3, 77, 96, device=DEV, dtype=dtype)
+    with torch.no_grad():
+        ref = copy.deepcopy(seq).double()(x.double())
+        y = fused(x)
+    assert _rel(y, ref) < 3e-3
+
+
+def test_paged_kv_cache_decode_loop():
+    """PagedKVCache (inference.py:1150-1303) driving reshape_and_cache + paged decode for ragged sequences, token by
+    token, against dense attention over everything written so far."""
+    from mio import ops
+    from mio.baseline.inference import PagedKVCache
+    torch.manual_seed(5)
+    H, D, L, bs, dtype = 4, 64, 2, 16, torch.float16
+    pc = PagedKVCache(num_blocks=24, block_size=bs, num_layers=L, num_heads=H, head_dim=D, dtype=dtype, device=DEV)
+    k_cache, v_cache = pc.get_physical_caches()
+    lens0 = [37, 5, 16]
+    hist = {s: ([], []) for s in range(len(lens0))}
+    layer = 1
+    for step in range(max(lens0) + 3):
+        active = [s for s, n in enumerate(lens0) if step < n + 3]
+        for s in active:
+            pc.append_token(s)
+        bt, cl, mx = pc.kernel_metadata(active)
+        kk = torch.randn(len(active), 1, H, D, dtype=dtype)   # [B, 1, Hkv, D] (attention_kernels.py:1314-1323)
+        vv = torch.randn(len(active), 1, H, D, dtype=dtype)
+        for i, s in enumerate(active):
+            hist[s][0].append(kk[i, 0])
+            hist[s][1].append(vv[i, 0])
+        ops.reshape_and_cache(kk.to(DEV), vv.to(DEV), k_cache, v_cache, bt, cl, bs, layer)
+        if step % 7 == 0 or step >= max(lens0):
+            q = torch.randn(len(active), H, 1, D, dtype=dtype)
+            o = torch.empty(len(active), H, 1, D, dtype=dtype, device=DEV)
+            ops.paged_attention_forward(q.to(DEV), o, k_cache, v_cache, bt, cl, bs, mx, layer)
+            for i, s in enumerate(active):
+                K = torch.stack(hist[s][0], 0)[None].double()   # [1, S, H, D]
+                V = torch.stack(hist[s][1], 0)[None].double()
+                ref = oracle.standard_attention(q[i].permute(1, 0, 2)[None].double(), K, V)[0].permute(1, 0, 2)
+                assert _rel(o[i], ref) < 2e-3, (step, s)
+    assert (k_cache[:, 0] == 0).all()  # the other layer of the cache was never touched
+    for s in range(len(lens0)):
+        pc.free_sequence(s)
+    assert pc.get_memory_usage()["free_physical_blocks"] == 24

@@ -175,3 +175,89 @@ def test_comm_wrappers_single_process():
     assert get_rank() == 0 and get_world_size() == 1
     assert all_reduce(t) is t and all_gather(t) is t and reduce_scatter(t) is t
     assert ring_exchange(t, None)[0] is t
+
+
+def test_fusion_registry_host_logic():
+    """FusionRegistry API of baseline/inference.py:26-215: pattern matching, non-overlapping candidates, replacement
+    inside nn.Sequential and attribute-style parents, weights carried over (module construction is host work)."""
+    from mio.baseline.inference import FusionPattern, FusionRegistry, fusion_registry
+    from mio.kernels.mlp.fused_mlp import FusedMLP, FusedMLPGeluTanh, FusedMLPReLU
+    assert [p.name for p in fusion_registry.patterns] == ["linear_gelu_linear", "linear_relu_linear"]
+    seq = nn.Sequential(nn.LayerNorm(8), nn.Linear(8, 32), nn.GELU(approximate="tanh"), nn.Linear(32, 8),
+                        nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 8), nn.Linear(8, 24), nn.GELU(), nn.Linear(24, 6))
+    fused = fusion_registry.fuse_modules(seq)
+    kinds = [type(m).__name__ for m in fused]
+    # the last triple does not map back to its input width (24 -> 6 != 8): left alone
+    assert kinds == ["LayerNorm", "FusedMLPGeluTanh", "FusedMLPReLU", "Linear", "GELU", "Linear"]
+    assert len(seq) == 10  # not in place by default
+    assert torch.equal(fused[1].fc1.weight, seq[1].weight) and torch.equal(fused[2].fc2.bias, seq[6].bias)
+
+    class Blk(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc_in, self.act, self.fc_out = nn.Linear(8, 16), nn.GELU(), nn.Linear(16, 8)
+    b = fusion_registry.fuse_modules(Blk(), inplace=True)
+    assert isinstance(b.fc_in, FusedMLP) and not isinstance(b.fc_in, (FusedMLPGeluTanh, FusedMLPReLU))
+    assert not hasattr(b, "act") and not hasattr(b, "fc_out")
+
+    reg = FusionRegistry()
+    reg.register_pattern(FusionPattern("pair", [nn.ReLU, nn.ReLU], lambda ms: nn.Identity()))
+    assert reg.find_matching_pattern([nn.ReLU(), nn.ReLU()]).name == "pair"
+    assert reg.find_matching_pattern([nn.ReLU(), nn.GELU()]) is None
+    assert [type(m).__name__ for m in reg.fuse_modules(nn.Sequential(nn.ReLU(), nn.ReLU(), nn.ReLU()))] == ["Identity", "ReLU"]
+
+
+def test_paged_kv_cache_allocator():
+    """BlockManager / PagedKVCache semantics of baseline/inference.py:1045-1303 (host bookkeeping; cache on CPU here)."""
+    from mio.baseline.inference import PagedKVCache
+    pc = PagedKVCache(num_blocks=6, block_size=4, num_layers=2, num_heads=2, head_dim=8, dtype=torch.float16, device="cpu")
+    k, v = pc.get_physical_caches()
+    assert tuple(k.shape) == (6, 2, 4, 2, 8) and tuple(v.shape) == tuple(k.shape)
+    pc.allocate_blocks_for_sequence(0, 9)           # 3 blocks
+    assert len(pc.get_block_table(0)) == 3 and pc.get_sequence_length(0) == 9
+    for _ in range(3):
+        pc.append_token(0)                           # 10, 11, 12 -> still 3 blocks
+    assert len(pc.get_block_table(0)) == 3 and pc.get_sequence_length(0) == 12
+    pc.append_token(0)                               # 13 -> 4th block
+    assert len(pc.get_block_table(0)) == 4
+    pc.append_token(7)                               # new sequence via append
+    assert pc.get_sequence_length(7) == 1 and len(pc.get_block_table(7)) == 1
+    assert len(set(pc.get_block_table(0)) | set(pc.get_block_table(7))) == 5
+    bt, cl, mx = pc.kernel_metadata([0, 7])
+    assert bt.dtype == torch.int32 and tuple(bt.shape) == (2, 4) and cl.tolist() == [13, 1] and mx == 13
+    assert bt[0].tolist() == pc.get_block_table(0) and bt[1, 0].item() == pc.get_block_table(7)[0]
+    with pytest.raises(MemoryError):                 # 1 block left, 3 needed: raises and frees the sequence
+        pc.allocate_blocks_for_sequence(9, 12)
+    assert pc.get_sequence_length(9) == 0
+    with pytest.raises(ValueError):
+        pc.get_block_table(9)
+    bm = pc.block_manager
+    blk = pc.get_block_table(7)[0]
+    bm.increase_ref_count(blk)
+    pc.free_sequence(7)
+    assert blk not in bm.free_blocks                 # still referenced once
+    bm.free_block(blk)
+    assert blk in bm.free_blocks
+    pc.free_sequence(0)
+    u = pc.get_memory_usage()
+    assert u["free_physical_blocks"] == 6 and u["active_sequences"] == 0 and u["gpu_cache_k_shape"] == (6, 2, 4, 2, 8)
+
+
+def test_ring_attention_config_and_shells():
+    """RingAttentionConfig validation (ring_attention.py:65-89) and the parameter names of the module shells."""
+    from mio.kernels.attention import RingAttentionConfig, RingCrossAttention, RingSelfAttention
+    for bad in (dict(world_size=0), dict(chunk_size=0), dict(precision="fp8"), dict(attention_dropout=1.0)):
+        with pytest.raises(ValueError):
+            RingAttentionConfig(**bad)
+    assert RingAttentionConfig(precision="fp16").compute_dtype == torch.float16
+    with pytest.raises(ValueError):
+        RingSelfAttention(30, 4, RingAttentionConfig())
+    fused = RingSelfAttention(32, 4, RingAttentionConfig(fuse_qkv=True))
+    split = RingSelfAttention(32, 4, RingAttentionConfig(fuse_qkv=False))
+    cross = RingCrossAttention(32, 4, RingAttentionConfig())
+    assert {n for n, _ in fused.named_parameters()} == {"qkv_proj.weight", "qkv_proj.bias", "out_proj.weight", "out_proj.bias"}
+    names = {"q_proj.weight", "q_proj.bias", "k_proj.weight", "k_proj.bias", "v_proj.weight", "v_proj.bias",
+             "out_proj.weight", "out_proj.bias"}
+    assert {n for n, _ in split.named_parameters()} == names == {n for n, _ in cross.named_parameters()}
+    with pytest.raises(ValueError):  # CPU tensor: no fallback
+        cross(torch.zeros(1, 4, 32), torch.zeros(1, 4, 32))
