@@ -415,6 +415,84 @@ def reshape_and_cache(key, value, k_cache, v_cache, block_tables, context_length
                                     bt.shape[1], dt, _stream()))
 
 
+# ------------------------------------------------------------------------------------------------
+# composed entry points: QKV projection + attention + out-projection, LayerNorm + QKV projection
+# ------------------------------------------------------------------------------------------------
+def fused_attention(hidden_states: torch.Tensor, qkv_weight: torch.Tensor, qkv_bias: Optional[torch.Tensor],
+                    out_weight: torch.Tensor, out_bias: Optional[torch.Tensor], mask: Optional[torch.Tensor] = None,
+                    causal: bool = False, num_heads: int = 8, head_dim: Optional[int] = None, dropout_p: float = 0.0,
+                    softmax_scale: Optional[float] = None, block_size: int = 128) -> torch.Tensor:
+    """Drop-in for triton_fused_attention (flash_attention_kernels.py:1361-1530): hidden [B,S,d],
+    qkv_weight [3d,d], out_weight [d,d].  Three launches (QKV GEMM, tiled attention reading q/k/v as strided views
+    of the QKV result, out-projection GEMM); nothing is copied in between."""
+    if hidden_states.dim() != 3:
+        raise ValueError(f"Expected 3D input tensor, got shape: {hidden_states.shape}")
+    B, S, d = hidden_states.shape
+    D = head_dim if head_dim is not None else d // num_heads
+    if num_heads * D != d or qkv_weight.shape[0] != 3 * d:
+        raise ValueError(f"hidden_size {d} does not match num_heads {num_heads} x head_dim {D} / qkv_weight "
+                         f"{tuple(qkv_weight.shape)}")
+    qkv = gemm_bias_act(hidden_states, qkv_weight, qkv_bias).view(B, S, 3, num_heads, D)
+    ctx = flash_attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], mask=mask, causal=causal,
+                          softmax_scale=softmax_scale, dropout_p=dropout_p, block_size=block_size)
+    return gemm_bias_act(ctx.view(B, S, d), out_weight, out_bias)
+
+
+def _infer_heads(hidden_size: int, num_heads: int) -> int:
+    if num_heads:
+        return num_heads
+    for hs in (64, 80, 128):  # fused_layernorm_qkv.py:653-663
+        if hidden_size % hs == 0:
+            return hidden_size // hs
+    return max(1, hidden_size // 64)
+
+
+def fused_layernorm_qkv(hidden_states, layernorm_weight, layernorm_bias, query_weight, key_weight, value_weight,
+                        query_bias=None, key_bias=None, value_bias=None, eps: float = 1e-5, num_heads: int = 0,
+                        num_kv_heads: Optional[int] = None):
+    """Drop-in for triton_fused_layernorm_qkv / pytorch_fused_layernorm_qkv (fused_layernorm_qkv.py:422-700):
+    returns (q [B,S,H,Dh], k [B,S,Hkv,Dkv], v [B,S,Hkv,Dkv]).
+
+    Two kernel kinds: the row-wise LayerNorm (HBM-bound, ~3 % of a layer at the benchmark shape) and the MFMA GEMM
+    whose operand tiles are moved global -> LDS by DMA; normalising inside that GEMM would put every activation
+    tile through registers and the vector ALU, which costs the matrix pipeline more than the one [B,S,d] round
+    trip it saves."""
+    if hidden_states.dim() != 3:
+        raise ValueError(f"Expected 3D input tensor, got shape: {hidden_states.shape}")
+    B, S, d = hidden_states.shape
+    H = _infer_heads(d, num_heads)
+    Hkv = H if num_kv_heads is None else num_kv_heads
+    xn = layernorm(hidden_states, layernorm_weight, layernorm_bias, eps)
+    q = gemm_bias_act(xn, query_weight, query_bias)
+    k = gemm_bias_act(xn, key_weight, key_bias)
+    v = gemm_bias_act(xn, value_weight, value_bias)
+    return (q.view(B, S, H, q.shape[-1] // H), k.view(B, S, Hkv, k.shape[-1] // Hkv),
+            v.view(B, S, Hkv, v.shape[-1] // Hkv))
+
+
+def flash_compatible_wrapper(hidden_states, layernorm_weight, layernorm_bias, qkv_weight, qkv_bias=None,
+                             eps: float = 1e-5, num_heads: int = 0, num_kv_heads: Optional[int] = None):
+    """fused_layernorm_qkv.py:1073-1116: combined [3d,d] QKV weight -> ONE GEMM; q/k/v are strided views of it."""
+    if hidden_states.dim() != 3:
+        raise ValueError(f"Expected 3D input tensor, got shape: {hidden_states.shape}")
+    B, S, d = hidden_states.shape
+    H = _infer_heads(d, num_heads)
+    Hkv = H if num_kv_heads is None else num_kv_heads
+    xn = layernorm(hidden_states, layernorm_weight, layernorm_bias, eps)
+    qkv = gemm_bias_act(xn, qkv_weight, qkv_bias)
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    return q.view(B, S, H, d // H), k.view(B, S, Hkv, d // Hkv), v.view(B, S, Hkv, d // Hkv)
+
+
+def ring_compatible_wrapper(hidden_states, layernorm_weight, layernorm_bias, q_weight, k_weight, v_weight,
+                            q_bias=None, k_bias=None, v_bias=None, eps: float = 1e-5, num_heads: int = 0,
+                            num_kv_heads: Optional[int] = None):
+    """fused_layernorm_qkv.py:1118-1161: as fused_layernorm_qkv, head-major [B,H,S,Dh] views for ring attention."""
+    q, k, v = fused_layernorm_qkv(hidden_states, layernorm_weight, layernorm_bias, q_weight, k_weight, v_weight,
+                                  q_bias, k_bias, v_bias, eps, num_heads, num_kv_heads)
+    return q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)
+
+
 # reference-name aliases (drop-in for code written against the Triton wrappers)
 triton_flash_attention = flash_attention
 triton_ring_attention_forward = ring_attention_forward
@@ -422,3 +500,5 @@ triton_fused_mlp = fused_mlp
 triton_layernorm = layernorm
 triton_paged_attention_forward = paged_attention_forward
 triton_reshape_and_cache = reshape_and_cache
+triton_fused_attention = fused_attention
+triton_fused_layernorm_qkv = fused_layernorm_qkv

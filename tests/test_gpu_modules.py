@@ -243,3 +243,35 @@ def test_paged_kv_cache_decode_loop():
     for s in range(len(lens0)):
         pc.free_sequence(s)
     assert pc.get_memory_usage()["free_physical_blocks"] == 24
+
+
+def test_composed_functional_entry_points():
+    """fused_attention (flash_attention_kernels.py:1361-1530) and fused LayerNorm + QKV with its two adapters
+    (fused_layernorm_qkv.py:422-700, 1073-1161) against the same math in fp64 on the CPU."""
+    from mio import ops
+    torch.manual_seed(6)
+    B, S, d, H, dtype = 2, 130, 128, 2, torch.float16
+    x = torch.randn(B, S, d, dtype=dtype)
+    wqkv, bqkv = (torch.randn(3 * d, d) * 0.06).to(dtype), (torch.randn(3 * d) * 0.1).to(dtype)
+    wo, bo = (torch.randn(d, d) * 0.06).to(dtype), (torch.randn(d) * 0.1).to(dtype)
+    g, b = (1 + 0.1 * torch.randn(d)).to(dtype), (0.1 * torch.randn(d)).to(dtype)
+    dev = lambda *ts: [t.to(DEV) for t in ts]
+    y = ops.triton_fused_attention(*dev(x, wqkv, bqkv, wo, bo), causal=True, num_heads=H)
+    qkv = F.linear(x.double(), wqkv.double(), bqkv.double()).view(B, S, 3, H, d // H)
+    ref = oracle.standard_attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], causal=True).reshape(B, S, d)
+    ref = F.linear(ref, wo.double(), bo.double())
+    assert _rel(y, ref) < 3e-3
+
+    xn = F.layer_norm(x.double(), (d,), g.double(), b.double(), 1e-5)
+    qr, kr, vr = (F.linear(xn, wqkv.double()[i * d:(i + 1) * d], bqkv.double()[i * d:(i + 1) * d]) for i in range(3))
+    q, k, v = ops.flash_compatible_wrapper(*dev(x, g, b, wqkv, bqkv), num_heads=H)
+    assert tuple(q.shape) == (B, S, H, d // H)
+    for got, want in ((q, qr), (k, kr), (v, vr)):
+        assert _rel(got.reshape(B, S, d), want) < 3e-3
+    ws = [wqkv[i * d:(i + 1) * d].contiguous() for i in range(3)]
+    bs = [bqkv[i * d:(i + 1) * d].contiguous() for i in range(3)]
+    q2, k2, v2 = ops.triton_fused_layernorm_qkv(*dev(x, g, b, *ws, *bs), num_heads=H)
+    assert torch.equal(q2, q) and torch.equal(k2, k) and torch.equal(v2, v)
+    q3, k3, v3 = ops.ring_compatible_wrapper(*dev(x, g, b, *ws, *bs), num_heads=H)
+    assert tuple(q3.shape) == (B, H, S, d // H) and torch.equal(q3.permute(0, 2, 1, 3), q)
+    assert ops._infer_heads(1280, 0) == 20 and ops._infer_heads(1024, 0) == 16 and ops._infer_heads(96, 0) == 1
