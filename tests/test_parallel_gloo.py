@@ -170,6 +170,41 @@ def _w_sp_modules(rank, world):
 
 
 # ---------------------------------------------------------------- tests
+def _w_tp_x_sp(rank, world):
+    """tensor (2) x sequence (2) mesh: heads split over the tensor group, the sequence over the sequence group; the
+    attention block of every rank = its slice of the dense result, and the row-parallel out-projection summed over
+    the tensor group = the dense block output for the rank's tokens."""
+    from mio.parallelism import communication as comm
+    from mio.parallelism.parallel_utils import (ParallelConfig, get_process_group_for_operation, group_ranks,
+                                                initialize_parallel_groups)
+    from mio.parallelism.sequence_parallel import ring_attention
+    cfg = ParallelConfig(world, tensor_parallel_size=2, sequence_parallel_size=2)
+    assert group_ranks(cfg, 3) == {"tensor": [2, 3], "sequence": [1, 3], "data": [3]}
+    groups = initialize_parallel_groups(cfg)
+    assert groups["data"] is None and get_process_group_for_operation("tensor") is groups["tensor"]
+    tp_r, sp_r = comm.get_rank(groups["tensor"]), comm.get_rank(groups["sequence"])
+    assert (tp_r, sp_r) == (rank % 2, rank // 2)
+    one = torch.ones(1)
+    assert comm.all_reduce(one.clone() * rank, "sum", group=groups["tensor"]).item() == sum(group_ranks(cfg, rank)["tensor"])
+    assert comm.all_reduce(one.clone() * rank, "sum", group=groups["sequence"]).item() == sum(group_ranks(cfg, rank)["sequence"])
+
+    torch.manual_seed(0)  # same tensors on every rank
+    B, S, H, D = 1, 32, 4, 8
+    d = H * D
+    q, k, v = (torch.randn(B, H, S, D) for _ in range(3))
+    wo = torch.randn(d, d) * 0.1
+    dense = torch.softmax((q @ k.transpose(-1, -2)) / D ** 0.5, dim=-1) @ v   # [B,H,S,D]
+    y_dense = dense.permute(0, 2, 1, 3).reshape(B, S, d) @ wo.T       # [B,S,d]
+    hs = slice(tp_r * H // 2, (tp_r + 1) * H // 2)
+    ss = slice(sp_r * S // 2, (sp_r + 1) * S // 2)
+    o = ring_attention(q[:, hs, ss].contiguous(), k[:, hs, ss].contiguous(), v[:, hs, ss].contiguous(),
+                       groups["sequence"], layout="bhsd", exchange="ring")
+    assert torch.allclose(o, dense[:, hs, ss], atol=1e-5)
+    part = o.permute(0, 2, 1, 3).reshape(B, S // 2, d // 2) @ wo[:, tp_r * d // 2:(tp_r + 1) * d // 2].T
+    y = comm.all_reduce(part, "sum", group=groups["tensor"])
+    assert torch.allclose(y, y_dense[:, ss], atol=1e-4)
+
+
 def test_collectives_ws2():
     _run("_w_collectives", 2)
 
@@ -201,3 +236,7 @@ def test_ring_attention_additive_mask_ws2():
 
 def test_sequence_parallel_modules_ws2():
     _run("_w_sp_modules", 2)
+
+
+def test_tensor_x_sequence_groups_ws4():
+    _run("_w_tp_x_sp", world=4)
