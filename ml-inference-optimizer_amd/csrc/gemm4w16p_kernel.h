@@ -271,14 +271,11 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
           const f32x4_t b = G6AccIO<nt * 8 + mt + 1>::read();
           G6AccIO<nt * 8 + mt>::zero();
           G6AccIO<nt * 8 + mt + 1>::zero();
-          float va[4], vb[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            va[e] = gemm_act<ACT>(a[e] + (float)bv[e]);
-            vb[e] = gemm_act<ACT>(b[e] + (float)bv[e]);
-          }
-          const auto s0 = __builtin_amdgcn_permlane16_swap(pack2<T>(va[0], va[1]), pack2<T>(vb[0], vb[1]), false, false);
-          const auto s1 = __builtin_amdgcn_permlane16_swap(pack2<T>(va[2], va[3]), pack2<T>(vb[2], vb[3]), false, false);
+          const f32x2_t b01 = {(float)bv[0], (float)bv[1]}, b23 = {(float)bv[2], (float)bv[3]};
+          const f32x2_t a01 = gemm_act2<ACT>((f32x2_t){a[0], a[1]} + b01), a23 = gemm_act2<ACT>((f32x2_t){a[2], a[3]} + b23);
+          const f32x2_t c01 = gemm_act2<ACT>((f32x2_t){b[0], b[1]} + b01), c23 = gemm_act2<ACT>((f32x2_t){b[2], b[3]} + b23);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(pack2<T>(a01[0], a01[1]), pack2<T>(c01[0], c01[1]), false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(pack2<T>(a23[0], a23[1]), pack2<T>(c23[0], c23[1]), false, false);
           ob0[mtp * 8 + nt] = s0[0];
           ob1[mtp * 8 + nt] = s1[0];
           ob2[mtp * 8 + nt] = s0[1];

@@ -52,6 +52,26 @@ __device__ __forceinline__ float gemm_act(float v) {
   return v;
 }
 
+// Two values at once with packed fp32 math (v_pk_mul/fma/add_f32): used where no MFMA is in flight (the read-out of
+// the persistent kernel), where packed ops run at twice the rate of the scalar forms.  Same formulas as gemm_act,
+// constants folded: gelu_tanh(v) = v / (1 + 2^(-v (c0 + c1 v^2))), c0 = 2 sqrt(2/pi) log2(e), c1 = 0.044715 c0.
+template <int ACT>
+__device__ __forceinline__ f32x2_t gemm_act2(f32x2_t v) {
+  if constexpr (ACT == MIO_ACT_GELU_TANH) {
+    constexpr float c0 = 2.0f * 0.7978845608028654f * 1.4426950408889634f, c1 = c0 * 0.044715f;
+    const f32x2_t t = v * v;
+    const f32x2_t z = -(v * (t * c1 + c0));
+    const f32x2_t d = (f32x2_t){fast_exp2(z[0]), fast_exp2(z[1])} + 1.0f;
+    return v * (f32x2_t){fast_rcp(d[0]), fast_rcp(d[1])};
+  } else if constexpr (ACT == MIO_ACT_SILU) {
+    const f32x2_t z = v * -1.4426950408889634f;
+    const f32x2_t d = (f32x2_t){fast_exp2(z[0]), fast_exp2(z[1])} + 1.0f;
+    return v * (f32x2_t){fast_rcp(d[0]), fast_rcp(d[1])};
+  } else {
+    return (f32x2_t){gemm_act<ACT>(v[0]), gemm_act<ACT>(v[1])};
+  }
+}
+
 // XCD-aware, grouped tile order: consecutive ids (round-robin over the 8 XCDs) are folded so each
 // XCD walks a contiguous run of tiles; inside a run GROUP_M row-tiles share each weight tile.
 __device__ __forceinline__ void gemm_tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {

@@ -4,6 +4,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${1:-r01}
+rm -rf $OUT
 mkdir -p $OUT
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python bench.py --steps 3 --warmup 1 > $OUT/bench_stats.json 2> $OUT/bench_stats.err
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o k -- python bench.py --steps 1 --warmup 1 --no-extra > /dev/null 2> $OUT/pmc_fetch.err

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Turn one tools/collect_profiles.sh run (gpurun_out/prof_<tag>/) into the tracked files under profiles/:
+  <tag>_bench_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary of `python bench.py --steps 3 --warmup 1`
+  <tag>_bench_under_rocprof.json   the JSON line bench.py printed in that same run
+  <tag>_pmc_sq_summary.txt         per-kernel means of the SQ counters
+  pmc_traffic.json                 HBM bytes per launch per kernel (FETCH_SIZE*2 + WRITE_SIZE, KiB -> bytes), keyed by
+                                   the kernel names bench.py uses
+"""
+import csv, glob, json, os, re, shutil, sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+
+
+def short(name):
+    m = re.match(r"(?:void )?(\w+)<(.*)>\(", name) or re.match(r"(?:void )?(\w+)<(.*)>", name)
+    if not m:
+        return name[:60]
+    k, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
+    dt = {"__bf16": "bf16", "_Float16": "fp16", "__hip_bfloat16": "bf16"}.get(args[0], args[0])
+    if k in ("gemm4w16_kernel", "gemm4w16p_kernel", "gemm_bias_act_kernel"):
+        act = {"0": "none", "1": "gelu_tanh", "2": "gelu_erf", "3": "relu", "4": "silu", "5": "swiglu"}
+        i = 1 if k != "gemm_bias_act_kernel" else len(args) - 1
+        return f"{k}<{dt},{act.get(args[i], args[i])}>"
+    if k in ("fa3_fwd_kernel", "fa3_fwd2_kernel"):
+        return f"{k}<{dt},D{args[1]},{'causal' if args[2] in ('true', '1') else 'full'}>"
+    return f"{k}<{dt}>"
+
+
+def counter_means(path):
+    acc = defaultdict(lambda: defaultdict(list))
+    for row in csv.DictReader(open(path)):
+        name = row.get("Kernel_Name") or ""
+        if "at::native" in name or "rocclr" in name or not name:
+            continue
+        acc[short(name)][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+stats = glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True)
+if stats:
+    shutil.copy(stats[0], f"profiles/{tag}_bench_kernel_stats.csv")
+if os.path.exists(f"{src}/bench_stats.json"):
+    shutil.copy(f"{src}/bench_stats.json", f"profiles/{tag}_bench_under_rocprof.json")
+traffic = defaultdict(float)
+for sub, ctr, mul in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):
+    for p in glob.glob(f"{src}/{sub}/**/*counter_collection.csv", recursive=True):
+        for k, cs in counter_means(p).items():
+            if ctr in cs:
+                traffic[k] += cs[ctr] * 1024.0 * mul
+if traffic:
+    out = dict(sorted(traffic.items()))
+    out["_note"] = ("HBM-side bytes per launch of each kernel in `bench.py --steps 1 --warmup 1 --no-extra` on one MI355X: "
+                    "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (tools/collect_profiles.sh), "
+                    "value*1024 bytes, FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, "
+                    "MI355X_MICROARCH.md section HBM; the LayerNorm and attention rows land on their algorithmic 128 / "
+                    "256 MiB with that correction). Infinity-Cache hits are counted, so the GEMM rows include tile "
+                    "re-reads served on-die.  Names as in bench.py kernel_rooflines().")
+    json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+for p in glob.glob(f"{src}/pmc_sq/**/*counter_collection.csv", recursive=True):
+    with open(f"profiles/{tag}_pmc_sq_summary.txt", "w") as f:
+        for k, cs in counter_means(p).items():
+            f.write(k + "\n")
+            for c, v in sorted(cs.items()):
+                f.write(f"   {c:32s} mean={v:.4g}\n")
+print(open("profiles/pmc_traffic.json").read() if traffic else "no traffic")
