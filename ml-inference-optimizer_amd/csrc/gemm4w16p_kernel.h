@@ -6,7 +6,7 @@
 // trickle out during tile i+1:
 //   * end of a tile: the 256 accumulator registers are read out, bias + activation applied, packed to 16 bits,
 //     row-pair exchanged (v_permlane16_swap) into 32 x 16-byte chunks per lane held in VGPRs (four 32-dword
-//     register arrays ob0..ob3, one per dword of a chunk), and the accumulators are re-zeroed;
+//     register arrays ob0..ob3, one per dword of a chunk); the next tile's first K-tile restarts them with C = 0;
 //   * next tile: every K-tile issues SPK (1, 2 or 4) buffer_store_dwordx4 of the previous tile from its first
 //     micro-steps, chunk index = kt*SPK + s read with VGPR-relative addressing (the index is wave-uniform).  Row /
 //     column edges and "all chunks already sent" are handled by the buffer range check: such a lane gets an
@@ -53,15 +53,6 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
   const int co = (g ^ g6_swz(c16)) * 16;
   const int xbase = (wr * 128 + c16) * 64 + co;
   const int wbase = G6_XT + (wc * 128 + c16) * 64 + co;
-
-  {  // zero the accumulator file once; afterwards every read-out re-zeroes what it read
-    auto zero_all = [&](auto self, auto K) {
-      constexpr int k = decltype(K)::value;
-      G6AccIO<k>::zero();
-      if constexpr (k + 1 < 64) self(self, std::integral_constant<int, k + 1>{});
-    };
-    zero_all(zero_all, std::integral_constant<int, 0>{});
-  }
 
   // pending output of the previous tile: 32 chunks of 16 bytes per lane (dword c of chunk j = obc[j]) + where they go
   u32x32_t ob0, ob1, ob2, ob3;
@@ -137,13 +128,21 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
     constexpr int nt = decltype(NT)::value;
     fw[nt & 1] = __builtin_bit_cast(X8, *(const u32x4_t*)(buf + wbase + nt * 16 * 64));
   };
-  auto mfma4 = [&](auto RB, auto J) {
+  // FIRST: the first K-tile of an output tile starts the accumulators (C = 0): no zeroing pass over the file
+  auto mfma4 = [&](auto RB, auto J, auto FIRST_) {
     constexpr int rb = decltype(RB)::value, j = decltype(J)::value;
     constexpr int nt = j / 2, mt0 = (j % 2) * 4;
-    G6Acc<T, nt * 8 + mt0 + 0>::mfma(fw[nt & 1], fx[rb][mt0 + 0]);
-    G6Acc<T, nt * 8 + mt0 + 1>::mfma(fw[nt & 1], fx[rb][mt0 + 1]);
-    G6Acc<T, nt * 8 + mt0 + 2>::mfma(fw[nt & 1], fx[rb][mt0 + 2]);
-    G6Acc<T, nt * 8 + mt0 + 3>::mfma(fw[nt & 1], fx[rb][mt0 + 3]);
+    if constexpr (decltype(FIRST_)::value != 0) {
+      G6Acc<T, nt * 8 + mt0 + 0>::mfma0(fw[nt & 1], fx[rb][mt0 + 0]);
+      G6Acc<T, nt * 8 + mt0 + 1>::mfma0(fw[nt & 1], fx[rb][mt0 + 1]);
+      G6Acc<T, nt * 8 + mt0 + 2>::mfma0(fw[nt & 1], fx[rb][mt0 + 2]);
+      G6Acc<T, nt * 8 + mt0 + 3>::mfma0(fw[nt & 1], fx[rb][mt0 + 3]);
+    } else {
+      G6Acc<T, nt * 8 + mt0 + 0>::mfma(fw[nt & 1], fx[rb][mt0 + 0]);
+      G6Acc<T, nt * 8 + mt0 + 1>::mfma(fw[nt & 1], fx[rb][mt0 + 1]);
+      G6Acc<T, nt * 8 + mt0 + 2>::mfma(fw[nt & 1], fx[rb][mt0 + 2]);
+      G6Acc<T, nt * 8 + mt0 + 3>::mfma(fw[nt & 1], fx[rb][mt0 + 3]);
+    }
   };
   // store chunk `chunk` (wave-uniform; = mtp*8 + nt) of the previous tile; scalar branches only.  Three phases so
   // that each fits the shadow of one 4-MFMA micro-step: address, VGPR-relative read of the chunk, store.
@@ -169,15 +168,16 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
   // otherwise one whole store in each of micro-steps 12..12+SPK-1).  TAIL: the K-tile prefetched three ahead lies
   // past this tile -> K-tile kt+3-nk of the tile `setup` now describes (the next tile, or this one again when the
   // workgroup has no next tile: harmless, never read).
-  auto ktile = [&](auto RBv, int kt, auto TAILv) {
+  auto ktile = [&](auto RBv, int kt, auto TAILv) {  // TAILv: 0 plain, 1 tail, 2 first K-tile of the output tile
     using RB = decltype(RBv);
     using NRB = std::integral_constant<int, RB::value ^ 1>;
-    constexpr bool TAIL = decltype(TAILv)::value != 0;
+    constexpr bool TAIL = decltype(TAILv)::value == 1;
+    using FIRST = std::integral_constant<int, decltype(TAILv)::value == 2 ? 1 : 0>;
     const char* buf = smem + ((sbase + kt) & (G6_STAGES - 1)) * G6_BUF;
     const char* nbuf = smem + ((sbase + kt + 1) & (G6_STAGES - 1)) * G6_BUF;
     const int kl = TAIL ? kt + 3 - nk : kt + 3;
 #define G6P_STEP(J)                                                                        \
-    mfma4(RB{}, IC(J));                                                                    \
+    mfma4(RB{}, IC(J), FIRST{});                                                           \
     if constexpr ((J) % 2 == 0 && (J) / 2 + 1 < 8) read_w(buf, IC((J) / 2 + 1));          \
     if constexpr (SPK == 1) {                                                              \
       if constexpr ((J) >= 12 && (J) <= 14) store_phase(kt, IC((J) - 12));                 \
@@ -226,7 +226,9 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
       sr0 = __builtin_amdgcn_s_memrealtime();
     }
     // K-tiles 0 .. nk-4 prefetch inside this tile (nk is even and >= 8)
-    int kt = 0;
+    ktile(IC(0), 0, IC(2));
+    ktile(IC(1), 1, IC(0));
+    int kt = 2;
     for (; kt < nk - 4; kt += 2) {
       ktile(IC(0), kt, IC(0));
       ktile(IC(1), kt + 1, IC(0));
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
     sbase = (sbase + nk) & (G6_STAGES - 1);
     if constexpr (STAMP) st2 = __builtin_amdgcn_s_memtime();
 
-    // ---- read-out: accumulators -> bias/activation -> 16-bit -> row-pair exchange -> ob0..3; accumulators := 0
+    // ---- read-out: accumulators -> bias/activation -> 16-bit -> row-pair exchange -> ob0..3
     // (the last MFMAs must have retired before the accumulator file is read: no interlock for asm readers)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     {
@@ -269,8 +271,6 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
           const X4 bv = __builtin_bit_cast(X4, bq[nt]);
           const f32x4_t a = G6AccIO<nt * 8 + mt>::read();
           const f32x4_t b = G6AccIO<nt * 8 + mt + 1>::read();
-          G6AccIO<nt * 8 + mt>::zero();
-          G6AccIO<nt * 8 + mt + 1>::zero();
           const f32x2_t b01 = {(float)bv[0], (float)bv[1]}, b23 = {(float)bv[2], (float)bv[3]};
           const f32x2_t a01 = gemm_act2<ACT>((f32x2_t){a[0], a[1]} + b01), a23 = gemm_act2<ACT>((f32x2_t){a[2], a[3]} + b23);
           const f32x2_t c01 = gemm_act2<ACT>((f32x2_t){b[0], b[1]} + b01), c23 = gemm_act2<ACT>((f32x2_t){b[2], b[3]} + b23);
