@@ -164,14 +164,7 @@ __global__ __launch_bounds__(256) void gemm4w16_kernel(const GemmDev p) {
   // 64 accumulator tiles of 4 registers live in the accumulator file a[0:255], owned by inline asm (tile
   // (nt, mt) = a[4*(8*nt+mt) ..+3]): left to hipcc, 64 independent 4-register accumulators get shuffled
   // between AGPRs and VGPRs inside the loop (4 v_accvgpr moves per MFMA).
-  {
-    auto zero_all = [&](auto self, auto K) {
-      constexpr int k = decltype(K)::value;
-      G6AccIO<k>::zero();
-      if constexpr (k + 1 < 64) self(self, std::integral_constant<int, k + 1>{});
-    };
-    zero_all(zero_all, std::integral_constant<int, 0>{});
-  }
+  // (the first K-tile starts them with C = 0: no zeroing pass)
 
   // fragment read offsets: lane reads row base + c16, stored chunk g ^ f(row)
   const int co = (g ^ g6_swz(c16)) * 16;
@@ -190,13 +183,20 @@ __global__ __launch_bounds__(256) void gemm4w16_kernel(const GemmDev p) {
     constexpr int nt = decltype(NT)::value;
     fw[nt & 1] = __builtin_bit_cast(X8, *(const u32x4_t*)(buf + wbase + nt * 16 * 64));
   };
-  auto mfma4 = [&](auto RB, auto J) {  // MFMAs 4j .. 4j+3 of the K-tile (nt-major order): nt = j/2, mt = (j%2)*4 ..
+  auto mfma4 = [&](auto RB, auto J, auto FIRST_) {  // MFMAs 4j .. 4j+3 of the K-tile (nt-major): nt = j/2, mt = (j%2)*4 ..
     constexpr int rb = decltype(RB)::value, j = decltype(J)::value;
     constexpr int nt = j / 2, mt0 = (j % 2) * 4;
-    G6Acc<T, nt * 8 + mt0 + 0>::mfma(fw[nt & 1], fx[rb][mt0 + 0]);
-    G6Acc<T, nt * 8 + mt0 + 1>::mfma(fw[nt & 1], fx[rb][mt0 + 1]);
-    G6Acc<T, nt * 8 + mt0 + 2>::mfma(fw[nt & 1], fx[rb][mt0 + 2]);
-    G6Acc<T, nt * 8 + mt0 + 3>::mfma(fw[nt & 1], fx[rb][mt0 + 3]);
+    if constexpr (decltype(FIRST_)::value != 0) {
+      G6Acc<T, nt * 8 + mt0 + 0>::mfma0(fw[nt & 1], fx[rb][mt0 + 0]);
+      G6Acc<T, nt * 8 + mt0 + 1>::mfma0(fw[nt & 1], fx[rb][mt0 + 1]);
+      G6Acc<T, nt * 8 + mt0 + 2>::mfma0(fw[nt & 1], fx[rb][mt0 + 2]);
+      G6Acc<T, nt * 8 + mt0 + 3>::mfma0(fw[nt & 1], fx[rb][mt0 + 3]);
+    } else {
+      G6Acc<T, nt * 8 + mt0 + 0>::mfma(fw[nt & 1], fx[rb][mt0 + 0]);
+      G6Acc<T, nt * 8 + mt0 + 1>::mfma(fw[nt & 1], fx[rb][mt0 + 1]);
+      G6Acc<T, nt * 8 + mt0 + 2>::mfma(fw[nt & 1], fx[rb][mt0 + 2]);
+      G6Acc<T, nt * 8 + mt0 + 3>::mfma(fw[nt & 1], fx[rb][mt0 + 3]);
+    }
   };
 
   unsigned long long t_begin = 0, t_loop0 = 0, t_loop1 = 0, r_begin = 0;
@@ -232,14 +232,15 @@ __global__ __launch_bounds__(256) void gemm4w16_kernel(const GemmDev p) {
   //                      fragments of K-tile kt+1 (other register buffer) + weight fragment 0 of K-tile kt+1
   // RAW: K-tile kt+1 is read only after every wave's counted wait and the barrier.  WAR: the refilled stage
   // (kt+3)%4 == (kt-1)%4 was last read in iteration kt-1, which every wave has left once it passes this barrier.
-  auto ktile = [&](auto RBv, int kt) {
+  auto ktile = [&](auto RBv, int kt, auto FIRSTv) {
     using RB = decltype(RBv);
     using NRB = std::integral_constant<int, RB::value ^ 1>;
+    using FIRST = decltype(FIRSTv);
     const char* buf = smem + (kt & (G6_STAGES - 1)) * G6_BUF;
     const char* nbuf = smem + ((kt + 1) & (G6_STAGES - 1)) * G6_BUF;
 #define IC(N) std::integral_constant<int, N>{}
 #define G6_MFMA_W(J)                                                   \
-    mfma4(RB{}, IC(J));                                                \
+    mfma4(RB{}, IC(J), FIRST{});                                       \
     if constexpr (!(VAR & 8) && (J) % 2 == 0 && (J) / 2 + 1 < 8) read_w(buf, IC((J) / 2 + 1));
     G6_MFMA_W(0) __builtin_amdgcn_sched_barrier(0);
     G6_MFMA_W(1) __builtin_amdgcn_sched_barrier(0);
@@ -270,12 +271,13 @@ __global__ __launch_bounds__(256) void gemm4w16_kernel(const GemmDev p) {
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   if constexpr (VAR & 32) t_loop0 = __builtin_amdgcn_s_memtime();
-  int kt = 0;
+  ktile(I0{}, 0, I1{});  // first K-tile: accumulators := a.b
+  int kt = 1;
   for (; kt + 1 < nk; kt += 2) {
-    ktile(I0{}, kt);
-    ktile(I1{}, kt + 1);
+    ktile(I1{}, kt, I0{});
+    ktile(I0{}, kt + 1, I0{});
   }
-  if (kt < nk) ktile(I0{}, kt);
+  if (kt < nk) ktile(I1{}, kt, I0{});
   if constexpr (VAR & 32) t_loop1 = __builtin_amdgcn_s_memtime();
 
   // the last MFMAs must have retired before the accumulator file is read (no interlock for asm readers)
