@@ -97,6 +97,14 @@ FA2_DEF(4, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79)
 FA2_DEF(5, 80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 90, 91, 92, 93, 94, 95)
 FA2_DEF(6, 96, 97, 98, 99, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111)
 FA2_DEF(7, 112, 113, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124, 125, 126, 127)
+// tiles 10..15 = a[160:255]: the top of the accumulator file (fa3_fwd3_kernel.h keeps its accumulators there, out of
+// the way of the low registers the allocator hands out first)
+FA2_DEF(10, 160, 161, 162, 163, 164, 165, 166, 167, 168, 169, 170, 171, 172, 173, 174, 175)
+FA2_DEF(11, 176, 177, 178, 179, 180, 181, 182, 183, 184, 185, 186, 187, 188, 189, 190, 191)
+FA2_DEF(12, 192, 193, 194, 195, 196, 197, 198, 199, 200, 201, 202, 203, 204, 205, 206, 207)
+FA2_DEF(13, 208, 209, 210, 211, 212, 213, 214, 215, 216, 217, 218, 219, 220, 221, 222, 223)
+FA2_DEF(14, 224, 225, 226, 227, 228, 229, 230, 231, 232, 233, 234, 235, 236, 237, 238, 239)
+FA2_DEF(15, 240, 241, 242, 243, 244, 245, 246, 247, 248, 249, 250, 251, 252, 253, 254, 255)
 #undef FA2_DEF
 
 // compile-time loop helper: f(integral_constant<int, I>) for I in [0, N)

@@ -1,0 +1,628 @@
+// FlashAttention forward, third structure (head dim 64, no user mask): software-pipelined across KV tiles.
+//
+// fa3_fwd2_kernel (one wave per SIMD, 64 query rows per wave) runs each tile as QK^T -> softmax -> PV in sequence, so
+// the matrix core idles during the softmax and the vector ALU idles during the MFMAs: 2375 cycles per tile against
+// 1024 of MFMA work (tools/fa_ab.py, rocprofv3 SQ counters).  Here, per wave and tile t:
+//   phase 1   S(t+1) = K(t+1) . Q~^T      20 MFMAs   ||   P(t) = exp2(S(t))        64 v_exp + 32 v_cvt_pk
+//   phase 2   O^T += V(t)^T . P(t)^T      24 MFMAs   ||   row max of S(t+1)        32 v_max3 (+ masks on edge tiles)
+// with S double-buffered in VGPRs.  What makes the two sides balance:
+//   * Q is pre-scaled by softmax_scale*log2(e) and the reference maximum is subtracted INSIDE the matrix core: one
+//     extra k-step per score tile multiplies a ones column on the K side (kone) with -reference on the Q side (qm),
+//     so the accumulators already hold the exp2 arguments (no v_fma per element);
+//   * row sums come from the matrix core too: L^T += ones(32x16) . P^T into a 32x32 accumulator whose registers all
+//     hold the row sum (no v_add per element);
+//   * every MFMA is an asm statement on asm-owned registers: O^T, L, Q~, qm, kone, ones live in the accumulator
+//     file (MFMA A/B operands may come from there), which leaves the 256 architectural VGPRs to S (128), P (32)
+//     and the K / V fragments -- and every phase is a fixed sequence of micro-steps (1 MFMA + its share of the
+//     vector work) pinned with sched_barrier(0).  (Compiler-visible "+a"/"a" operands were tried: accumulator
+//     tuples get copied at branch joins right behind an asm MFMA whose latency the compiler does not know -- lost
+//     updates -- and "a" inputs are re-copied from VGPRs before every use.)
+// The reference only moves when a row outgrows it by 2^FA_RESCALE_THR (flash_attention_kernels.py:276-298 is the
+// algorithm: online softmax with running max / sum; exp -> exp2).  K/V tiles go global -> LDS by DMA through a 4-stage
+// ring (K(t+1) and V(t) are read while tiles t+2 and t+3 are in flight: a tile has two iterations to land), one
+// barrier per tile.
+#pragma once
+#include "fa3_fwd2_kernel.h"
+
+constexpr int FA3_BM = 256;     // query rows per workgroup (4 waves x 64)
+constexpr int FA3_STAGES = 4;
+// Accumulator-file map (all asm-owned, at the TOP of the file: the allocator hands out a0, a1, ... for its own
+// values first; tools/check_agpr.py verifies after every build that no compiler-generated instruction touches a112+):
+//   Q~ fragment (qt, ks) = a[112 + 16 qt + 4 ks : +3]      qm[qt] = a[144 + 4 qt : +3]  (-reference at k = 0)
+//   kone = a[152:155] (A operand, ones at k = 0)            ones = a[156:159] (A operand, all ones)
+//   O^T tile qt*2+dt = Fa2Acc tile 10 + qt*2+dt = a[160:223]   L tile qt = Fa2Acc tile 14 + qt = a[224:255]
+constexpr int FA3_A_Q = 112, FA3_A_QM = 144, FA3_T_O = 10, FA3_T_L = 14;
+
+template <int R>
+struct Fa3AW;  // write one accumulator register (the clobber makes the register part of the kernel's allocation)
+#define FA3_AW(R)                                                                      \
+  template <>                                                                          \
+  struct Fa3AW<R> {                                                                    \
+    static __device__ __forceinline__ void w(uint32_t v) {                             \
+      asm volatile("v_accvgpr_write_b32 a" #R ", %0" : : "v"(v) : "a" #R);             \
+    }                                                                                  \
+  };
+FA3_AW(112)
+FA3_AW(113)
+FA3_AW(114)
+FA3_AW(115)
+FA3_AW(116)
+FA3_AW(117)
+FA3_AW(118)
+FA3_AW(119)
+FA3_AW(120)
+FA3_AW(121)
+FA3_AW(122)
+FA3_AW(123)
+FA3_AW(124)
+FA3_AW(125)
+FA3_AW(126)
+FA3_AW(127)
+FA3_AW(128)
+FA3_AW(129)
+FA3_AW(130)
+FA3_AW(131)
+FA3_AW(132)
+FA3_AW(133)
+FA3_AW(134)
+FA3_AW(135)
+FA3_AW(136)
+FA3_AW(137)
+FA3_AW(138)
+FA3_AW(139)
+FA3_AW(140)
+FA3_AW(141)
+FA3_AW(142)
+FA3_AW(143)
+FA3_AW(144)
+FA3_AW(145)
+FA3_AW(146)
+FA3_AW(147)
+FA3_AW(148)
+FA3_AW(149)
+FA3_AW(150)
+FA3_AW(151)
+FA3_AW(152)
+FA3_AW(153)
+FA3_AW(154)
+FA3_AW(155)
+FA3_AW(156)
+FA3_AW(157)
+FA3_AW(158)
+FA3_AW(159)
+#undef FA3_AW
+
+template <typename T>
+struct Fa3Ops;
+#define FA3_OPS(TY, SUF)                                                                                              \
+  template <>                                                                                                         \
+  struct Fa3Ops<TY> {                                                                                                 \
+    using X8 = typename DT<TY>::x8;                                                                                   \
+    /* S += K fragment (VGPR) . Q~ fragment a[R:R+3] */                                                               \
+    template <int R>                                                                                                  \
+    static __device__ __forceinline__ void qk(f32x16_t& acc, const X8& kf) {                                          \
+      asm volatile("v_mfma_f32_32x32x16_" SUF " %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(kf), "n"(R), "n"(R + 3));     \
+    }                                                                                                                 \
+    /* S = kone . qm fragment a[R:R+3]  (= -reference in every score of the row) */                                   \
+    template <int R>                                                                                                  \
+    static __device__ __forceinline__ void qk_ref(f32x16_t& acc) {                                                    \
+      asm volatile("v_mfma_f32_32x32x16_" SUF " %0, a[152:155], a[%1:%2], 0" : "=v"(acc) : "n"(R), "n"(R + 3));       \
+    }                                                                                                                 \
+    static __device__ __forceinline__ void lsum0(const X8& pf) {                                                      \
+      asm volatile("v_mfma_f32_32x32x16_" SUF " a[224:239], a[156:159], %0, a[224:239]"                               \
+                   :                                                                                                  \
+                   : "v"(pf)                                                                                          \
+                   : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235",  \
+                     "a236", "a237", "a238", "a239");                                                                 \
+    }                                                                                                                 \
+    static __device__ __forceinline__ void lsum1(const X8& pf) {                                                      \
+      asm volatile("v_mfma_f32_32x32x16_" SUF " a[240:255], a[156:159], %0, a[240:255]"                               \
+                   :                                                                                                  \
+                   : "v"(pf)                                                                                          \
+                   : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251",  \
+                     "a252", "a253", "a254", "a255");                                                                 \
+    }                                                                                                                 \
+  };
+FA3_OPS(__bf16, "bf16")
+FA3_OPS(_Float16, "f16")
+#undef FA3_OPS
+
+template <typename T, bool CAUSAL, bool STAMP = false>
+__global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
+  using X8 = typename DT<T>::x8;
+  using X4 = typename DT<T>::x4;
+  using OPS = Fa3Ops<T>;
+  constexpr int D = 64, QT = 2, KS = 4, DT_ = 2, CPR = 8, NLD = 2;
+  using SM = FaSmem<D>;
+#define IC(N) std::integral_constant<int, (N)> {}
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  int bh, qi;
+  {
+    const int id = blockIdx.x;
+    if (p.xcd_remap & 1) {
+      const int xcd = id & 7, slot = id >> 3;
+      bh = (slot / p.qgrid) * 8 + xcd;
+      qi = slot % p.qgrid;
+    } else {
+      bh = id / p.qgrid;
+      qi = id % p.qgrid;
+    }
+  }
+  const int b = bh / p.H, head = bh % p.H;
+  const int kvh = head / (p.H / p.Hkv);
+
+  // constant MFMA operands: kone = A operand with ones at k = 0, ones = A operand of all ones; qm registers 1..3 = 0
+  {
+    const uint32_t o2 = pack2<T>(1.f, 1.f), o1 = pack2<T>(h == 0 ? 1.f : 0.f, 0.f);
+    Fa3AW<152>::w(o1); Fa3AW<153>::w(0u); Fa3AW<154>::w(0u); Fa3AW<155>::w(0u);
+    Fa3AW<156>::w(o2); Fa3AW<157>::w(o2); Fa3AW<158>::w(o2); Fa3AW<159>::w(o2);
+    Fa3AW<145>::w(0u); Fa3AW<146>::w(0u); Fa3AW<147>::w(0u);
+    Fa3AW<149>::w(0u); Fa3AW<150>::w(0u); Fa3AW<151>::w(0u);
+  }
+
+  // per-lane LDS read offsets (layouts: fa3_fwd_kernel.h)
+  const int k_rd = r * SM::KROW + 16 * h;
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int v_rd = (4 * h + (i16 >> 2)) * 64 + 32 * (g16 & 1) + 8 * (i16 & 3);
+
+  // Causal: this workgroup handles query block nqblk-1-qi (heavy) and then block qi (light): equal work for every
+  // workgroup.  Non-causal: one block.
+  const int npass = (CAUSAL && (p.nqblk - 1 - qi) != qi) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int qblk = CAUSAL ? (pass == 0 ? p.nqblk - 1 - qi : qi) : qi;
+    const int q0 = qblk * FA3_BM;
+    const int wrow0 = q0 + wave * (32 * QT);  // first query row of this wave
+    int qrow[QT];
+    bool q_ok[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      qrow[qt] = wrow0 + 32 * qt + r;
+      q_ok[qt] = qrow[qt] < p.Sq;
+    }
+
+    // ---- Q~ = Q * softmax_scale * log2(e) as MFMA B fragments (lane (r,h) holds Q~[row][16ks + 8h .. +7])
+    fa2_for<QT * KS>([&](auto QK_) {
+      constexpr int qt = decltype(QK_)::value / KS, ks = decltype(QK_)::value % KS;
+      const T* qp = (const T*)p.q + b * p.qs_b + head * p.qs_h + (int64_t)(q_ok[qt] ? qrow[qt] : 0) * p.qs_s;
+      const int d0 = 16 * ks + 8 * h;
+      u32x4_t raw = *(const u32x4_t*)(qp + (d0 < p.D ? d0 : 0));
+      if (!(q_ok[qt] && d0 < p.D)) raw = (u32x4_t){0, 0, 0, 0};
+      const X8 q8 = __builtin_bit_cast(X8, raw);
+      constexpr int R = FA3_A_Q + 16 * qt + 4 * ks;
+      Fa3AW<R + 0>::w(pack2<T>((float)q8[0] * p.scale_log2e, (float)q8[1] * p.scale_log2e));
+      Fa3AW<R + 1>::w(pack2<T>((float)q8[2] * p.scale_log2e, (float)q8[3] * p.scale_log2e));
+      Fa3AW<R + 2>::w(pack2<T>((float)q8[4] * p.scale_log2e, (float)q8[5] * p.scale_log2e));
+      Fa3AW<R + 3>::w(pack2<T>((float)q8[6] * p.scale_log2e, (float)q8[7] * p.scale_log2e));
+    });
+
+    // ---- running state per query sub-tile: m_i = reference (exp2 domain, a value of type T so that it is exact as
+    // an MFMA operand; -inf = no finite score yet, the reference is then 0); qm = B fragment with -reference at k = 0;
+    // O^T tile qt*2+dt and the row-sum tile L[qt] (every register of a lane = the row sum)
+    float m_i[QT], lcarry[QT], rcarry[QT];
+    auto set_ref = [&](auto QTI, float ref) {
+      Fa3AW<FA3_A_QM + 4 * decltype(QTI)::value>::w(pack2<T>(h == 0 ? -ref : 0.f, 0.f));
+    };
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      m_i[qt] = -INFINITY;
+      float l0 = 0.f, ref0 = 0.f;
+      if (p.carry_in && q_ok[qt]) {
+        const float lse_in = p.lse[((int64_t)b * p.H + head) * p.Sq + qrow[qt]];
+        if (lse_in != -INFINITY) {  // carried state relative to a T-representable reference: l = 2^(lse - reference)
+          const float lse2 = lse_in * FA_LOG2E;
+          m_i[qt] = (float)(T)lse2;
+          l0 = fast_exp2(lse2 - m_i[qt]);
+          ref0 = m_i[qt];
+        }
+      }
+      lcarry[qt] = l0;
+      rcarry[qt] = ref0;
+    }
+    set_ref(IC(0), rcarry[0]);
+    set_ref(IC(1), rcarry[1]);
+    fa2_for<QT>([&](auto QTI) {
+      constexpr int qt = decltype(QTI)::value;
+      const f32x4_t lv = {lcarry[qt], lcarry[qt], lcarry[qt], lcarry[qt]};
+      Fa2AccIO<FA3_T_L + qt>::template write4<0>(lv);
+      Fa2AccIO<FA3_T_L + qt>::template write4<1>(lv);
+      Fa2AccIO<FA3_T_L + qt>::template write4<2>(lv);
+      Fa2AccIO<FA3_T_L + qt>::template write4<3>(lv);
+    });
+    fa2_for<QT * DT_>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      constexpr int qt = k / DT_, dt = k % DT_;
+      f32x4_t z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (p.carry_in && q_ok[qt]) {
+        const float* oa = p.o_acc + (((int64_t)b * p.Sq + qrow[qt]) * p.H + head) * p.D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = 32 * dt + 8 * g + 4 * h;
+          if (d0 < p.D) z[g] = *(const f32x4_t*)(oa + d0);
+        }
+      }
+      Fa2AccIO<FA3_T_O + k>::template write4<0>(z[0]);
+      Fa2AccIO<FA3_T_O + k>::template write4<1>(z[1]);
+      Fa2AccIO<FA3_T_O + k>::template write4<2>(z[2]);
+      Fa2AccIO<FA3_T_O + k>::template write4<3>(z[3]);
+    });
+    asm volatile("s_nop 7" ::: "memory");  // accumulator-file writes settle before the first MFMA reads them
+
+    // ---- tiles: the workgroup walks n_tiles (barriers, staging); this wave computes the first n_w of them
+    int n_tiles, n_w;
+    if (CAUSAL) {
+      int kmax = q0 + FA3_BM - 1 + p.q_offset - p.k_offset;
+      if (kmax > p.Sk - 1) kmax = p.Sk - 1;
+      n_tiles = kmax < 0 ? 0 : kmax / FA_BN + 1;
+      int kw = wrow0 + 32 * QT - 1 + p.q_offset - p.k_offset;
+      if (kw > p.Sk - 1) kw = p.Sk - 1;
+      n_w = kw < 0 ? 0 : kw / FA_BN + 1;
+    } else {
+      n_tiles = (p.Sk + FA_BN - 1) / FA_BN;
+      n_w = n_tiles;
+    }
+    const int n_tiles_dma = n_tiles > 0 ? n_tiles : 1;
+    // last key visible to each query row of this lane, and the first tile of this wave that needs masks
+    int klim[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      klim[qt] = p.Sk - 1;
+      if (CAUSAL) {
+        const int c = qrow[qt] + p.q_offset - p.k_offset;
+        klim[qt] = c < klim[qt] ? c : klim[qt];
+      }
+    }
+    // tile t is an edge tile iff its last key is past the limit of the wave's FIRST row (limits grow with the row)
+    int lim0 = p.Sk - 1;
+    if (CAUSAL) {
+      const int c = wrow0 + p.q_offset - p.k_offset;
+      lim0 = c < lim0 ? c : lim0;
+    }
+    const int first_edge = (lim0 + 1) / FA_BN;  // tiles t >= first_edge contain a key > lim0  (lim0 + 1 >= 0 here
+                                                // whenever n_w > 0 ... negative limits give first_edge <= 0: all edge)
+    auto is_edge = [&](int t) -> bool { return t >= first_edge; };
+
+    // ---- K/V staging: global -> LDS by DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB of lane-linear LDS per
+    // wave-instruction, no staging registers).  A stage is 17 such units: 0..8 the K tile (64 rows x 144 B: 9 chunks
+    // per row, the 9th is padding), 9..16 the V tile ([key/8][d/32][8][32] sub-tiles of 512 B); the per-lane SOURCE
+    // address realises the layout.  Wave w moves units w, w+4, w+8, w+12 and a fifth (16 for wave 0, its first unit
+    // again for the others: every wave then has exactly 5 loads per tile in flight, which is what the counted
+    // waits below assume).  Rows past Sk and chunks
+    // past D are clamped to valid data instead of zeroed: such keys are masked to -inf (edge tiles) and Q~ is zero
+    // past D, so the values only need to be finite.
+    const T* kbase = (const T*)p.k + b * p.ks_b + kvh * p.ks_h;
+    const T* vbase = (const T*)p.v + b * p.vs_b + kvh * p.vs_h;
+    const int d_chunks = p.D >> 3;
+    int st_row[5], st_cb[5];  // per unit slot: key row inside the tile, byte offset of the 16-B chunk in the row
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int u = (wave + 4 * i < 17) ? wave + 4 * i : wave;  // 5 units per wave (waves 1..3 repeat their first)
+      int row, c;
+      if (u < 9) {
+        const int u16 = 64 * u + lane;
+        row = u16 / 9;
+        c = u16 % 9;
+      } else {
+        const int blk = 2 * (u - 9) + (lane >> 5);
+        row = 8 * (blk >> 1) + ((lane & 31) >> 2);
+        c = 4 * (blk & 1) + (lane & 3);
+      }
+      c = c < d_chunks ? c : d_chunks - 1;
+      st_row[i] = row;
+      st_cb[i] = 16 * c;
+    }
+    // one DMA unit of tile `tile` (clamped to the last tile: a run past the end re-fetches valid data into a dead
+    // stage, which keeps the number of loads per iteration -- and the counted waits -- the same for every iteration)
+    const int ks2 = (int)p.ks_s * 2, vs2 = (int)p.vs_s * 2;  // row strides in bytes (< 2^24: 24-bit multiplies below)
+    const char* dma_kb = nullptr;  // scalar: first row of the K / V tile being fetched (set by dma_tile_base)
+    const char* dma_vb = nullptr;
+    int dma_last = 0;
+    auto dma_tile_base = [&](int tile_) {
+      const int tile = tile_ < n_tiles_dma ? tile_ : n_tiles_dma - 1;
+      const int kv0 = tile * FA_BN;
+      dma_kb = (const char*)(kbase + (int64_t)kv0 * p.ks_s);
+      dma_vb = (const char*)(vbase + (int64_t)kv0 * p.vs_s);
+      dma_last = p.Sk - 1 - kv0;  // last valid row of the tile (>= 63 for a full tile)
+    };
+    auto dma_unit = [&](auto I_, int tile_) {
+      constexpr int i = decltype(I_)::value;
+      const int stage = tile_ & (FA3_STAGES - 1);
+      const int u = (wave + 4 * i < 17) ? wave + 4 * i : wave;  // wave-uniform
+      const bool isk = u < 9;
+      const char* base = isk ? dma_kb : dma_vb;
+      const int row = st_row[i] < dma_last ? st_row[i] : dma_last;  // rows past Sk: clamped (branch-free)
+      const int off = (int)__umul24((unsigned)row, (unsigned)(isk ? ks2 : vs2)) + st_cb[i];
+      // asm: invisible to the compiler's wait-count insertion, which otherwise drains the DMA (vmcnt(0)) in front of
+      // the next LDS read it cannot prove disjoint -- the V fragments of the tile being computed
+      const uint32_t lds = (uint32_t)(size_t)((MIO_LDS char*)(smem + stage * SM::STAGE + 1024 * u));
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   :
+                   : "s"(lds), "v"(off), "s"(base)
+                   : "memory", "m0");
+    };
+    auto stage_dma = [&](int tile) {
+      dma_tile_base(tile);
+      dma_unit(IC(0), tile); dma_unit(IC(1), tile); dma_unit(IC(2), tile); dma_unit(IC(3), tile); dma_unit(IC(4), tile);
+    };
+
+    __syncthreads();  // the previous pass is done with every LDS stage
+    stage_dma(0);
+    stage_dma(1);
+    stage_dma(2);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // tiles 0 and 1 have landed, tile 2 may still fly
+    __syncthreads();
+
+    f32x16_t S[2][QT][2];   // score tiles: buffer (t & 1), query sub-tile, 32-key half
+    u32x4_t pfw[QT][4];     // P^T fragments of the tile in phase 2: k-step s (16 keys)
+    X8 vfr[2][DT_];         // V^T fragments, ring over k-steps
+    float mx[QT];
+
+    auto read_v = [&](const char* vb, auto S_) {
+      constexpr int s = decltype(S_)::value;
+#pragma unroll
+      for (int dt = 0; dt < DT_; ++dt) {
+        const X4 lo = DT<T>::ds_read_tr(vb + v_rd + ((2 * s + 0) * DT_ + dt) * 512);
+        const X4 hi = DT<T>::ds_read_tr(vb + v_rd + ((2 * s + 1) * DT_ + dt) * 512);
+        X8 f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        vfr[s & 1][dt] = f;
+      }
+    };
+
+    // ---- phase 1: S[cb ^ 1] = scores of the next tile (K at kb)  ||  P = exp2(S[cb])  (+ the first V fragments from vb).
+    // The QK^T half always runs (after the last tile of the wave it produces scores nobody reads): a run-time
+    // "has next" would put the shared vector half under two branches, and the compiler then hoists it out of the
+    // pinned micro-steps.
+    auto phase1 = [&](auto CB_, auto DO_EXP_, const char* kb, const char* vb) {
+      constexpr int cb = decltype(CB_)::value, nb = cb ^ 1;
+      constexpr bool DO_EXP = decltype(DO_EXP_)::value != 0;
+      X8 kf[2][2];
+      auto read_k = [&](auto KS_) {
+        constexpr int ks = decltype(KS_)::value;
+        kf[ks & 1][0] = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + k_rd + 32 * ks));
+        kf[ks & 1][1] = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + k_rd + 32 * SM::KROW + 32 * ks));
+      };
+      read_k(IC(0));
+      read_k(IC(1));
+      auto step = [&](auto J_) {
+        constexpr int j = decltype(J_)::value;
+        if constexpr (j < 4) {
+          OPS::template qk_ref<FA3_A_QM + 4 * (j >> 1)>(S[nb][j >> 1][j & 1]);
+        } else {
+          constexpr int ks = (j - 4) >> 2, qt = ((j - 4) & 3) >> 1, tt = (j - 4) & 1;
+          OPS::template qk<FA3_A_Q + 16 * qt + 4 * ks>(S[nb][qt][tt], kf[ks & 1][tt]);
+        }
+        if constexpr (j == 7) read_k(IC(2));
+        if constexpr (j == 11) read_k(IC(3));
+        if constexpr (DO_EXP && j >= 2 && j < 18) {
+          constexpr int i = j - 2, u = i >> 1, half = i & 1, qt = u >> 2, s = u & 3;
+          constexpr int base = 8 * (s & 1) + 4 * half;
+          const float e0 = fast_exp2(S[cb][qt][s >> 1][base + 0]);
+          const float e1 = fast_exp2(S[cb][qt][s >> 1][base + 1]);
+          const float e2 = fast_exp2(S[cb][qt][s >> 1][base + 2]);
+          const float e3 = fast_exp2(S[cb][qt][s >> 1][base + 3]);
+          const uint32_t w0 = pack2<T>(e0, e1), w1 = pack2<T>(e2, e3);
+          asm volatile("" ::"v"(w0), "v"(w1));  // a use in THIS block: keeps the exp / cvt work from sinking to phase 2
+          pfw[qt][s][2 * half + 0] = w0;
+          pfw[qt][s][2 * half + 1] = w1;
+        }
+        if constexpr (DO_EXP && j == 17) read_v(vb, IC(0));
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      fa2_for<20>(step);
+    };
+
+    // ---- masks of an edge tile (causal diagonal, keys past Sk) on S[nb]; first key kv0n.  Rare: not overlapped.
+    // Key kv0n + c + 4h (c = 32 tt + (i & 3) + 8 (i >> 2), a compile-time constant per register) is visible to query
+    // row q iff it is <= klim[q]: one compare against a per-lane threshold per element, in groups of 8 so that the
+    // compare results do not pile up in scalar registers.
+    auto mask_tile = [&](auto NB_, int kv0n) {
+      constexpr int nb = decltype(NB_)::value;
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results (asm) are read by the vector ALU next
+      fa2_for<QT>([&](auto QTI) {
+        constexpr int qt = decltype(QTI)::value;
+        const int thr = klim[qt] - kv0n - 4 * h;
+        fa2_for<4>([&](auto G_) {
+          constexpr int tt = decltype(G_)::value >> 1, i0 = 8 * (decltype(G_)::value & 1);
+#pragma unroll
+          for (int i = i0; i < i0 + 8; ++i) {
+            const int c = 32 * tt + (i & 3) + 8 * (i >> 2);
+            if (c > thr) S[nb][qt][tt][i] = -INFINITY;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+    };
+
+    // ---- phase 2: O^T += V^T . P^T, L += ones . P^T   ||   row max of S[nb] (the next tile)
+    auto phase2 = [&](auto NB_, auto DO_PV_, const char* vb, int dma_tile) {
+      constexpr int nb = decltype(NB_)::value;
+      constexpr bool DO_PV = decltype(DO_PV_)::value != 0;
+      auto step = [&](auto J_) {
+        constexpr int j = decltype(J_)::value;
+        constexpr int s = j / 6, m = j % 6;
+        if constexpr (DO_PV) {
+          if constexpr (m < 4) {
+            constexpr int dt = m >> 1, qt = m & 1;
+            Fa2Acc<T, FA3_T_O + qt * DT_ + dt>::mfma(vfr[s & 1][dt], __builtin_bit_cast(X8, pfw[qt][s]));
+          } else if constexpr (m == 4) {
+            OPS::lsum0(__builtin_bit_cast(X8, pfw[0][s]));
+          } else {
+            OPS::lsum1(__builtin_bit_cast(X8, pfw[1][s]));
+          }
+          if constexpr (m == 1 && s + 1 < 4) read_v(vb, IC(s + 1));  // slot (s+1)&1 was last read by k-step s-1
+          if constexpr (j % 5 == 3 && j / 5 < 5) dma_unit(IC(j / 5), dma_tile);  // steps 3, 8, 13, 18, 23: tile t + 3
+        }
+        if constexpr (j >= 4 && j < 20) {
+          constexpr int k = j - 4;  // 16 steps: three, then two more values per step
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) {
+            // element e of the 32 scores of this lane: tile e >> 4, register e & 15
+            auto val = [&](int e) { return S[nb][qt][e >> 4][e & 15]; };
+            if constexpr (k == 0) mx[qt] = fmaxf(fmaxf(val(0), val(1)), val(2));
+            else if constexpr (k == 15) mx[qt] = fmaxf(mx[qt], val(31));
+            else mx[qt] = fmaxf(fmaxf(mx[qt], val(2 * k + 1)), val(2 * k + 2));
+            asm volatile("" : "+v"(mx[qt]));  // pins this step's share of the max chain to this micro-step
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      fa2_for<24>(step);
+    };
+
+    // ---- reference update for the tile in S[nb] (rare after the first tiles: deferred-rescale threshold).  One
+    // wave-uniform test for both query sub-tiles; inside, a row that does not need to move gets delta = 0, alpha = 1.
+    auto update = [&](auto NB_) {
+      constexpr int nb = decltype(NB_)::value;
+      float mxr[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) mxr[qt] = fmaxf(mx[qt], other_half(mx[qt]));
+      const bool trig = (mxr[0] > FA_RESCALE_THR) || (m_i[0] == -INFINITY) || (mxr[1] > FA_RESCALE_THR) || (m_i[1] == -INFINITY);
+      if (__builtin_amdgcn_ballot_w64(trig) != 0) {
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs retired before the file is read
+        fa2_for<QT>([&](auto QTI) {
+          constexpr int qt = decltype(QTI)::value;
+          const bool fresh = (m_i[qt] == -INFINITY);
+          const float ref_old = fresh ? 0.f : m_i[qt];
+          const float m_new = (float)(T)fmaxf(m_i[qt], mxr[qt] + ref_old);  // the reference must be exact as a T operand
+          const float ref_new = (m_new == -INFINITY) ? 0.f : m_new;
+          const float delta = ref_new - ref_old;
+          const float alpha = fresh ? 1.f : fast_exp2(-delta);
+          m_i[qt] = m_new;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            S[nb][qt][0][i] -= delta;
+            S[nb][qt][1][i] -= delta;
+          }
+          auto rescale = [&](auto KI) {
+            constexpr int k = decltype(KI)::value;
+            f32x4_t v[4] = {Fa2AccIO<k>::template read4<0>(), Fa2AccIO<k>::template read4<1>(),
+                            Fa2AccIO<k>::template read4<2>(), Fa2AccIO<k>::template read4<3>()};
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[gq][e] *= alpha;
+            Fa2AccIO<k>::template write4<0>(v[0]);
+            Fa2AccIO<k>::template write4<1>(v[1]);
+            Fa2AccIO<k>::template write4<2>(v[2]);
+            Fa2AccIO<k>::template write4<3>(v[3]);
+          };
+          rescale(IC(FA3_T_O + qt * DT_ + 0));
+          rescale(IC(FA3_T_O + qt * DT_ + 1));
+          rescale(IC(FA3_T_L + qt));
+          set_ref(QTI, ref_new);
+        });
+        asm volatile("s_nop 7" ::: "memory");
+      }
+    };
+
+    // ---- scores, masks, maximum and reference of tile 0
+    if (n_w > 0) {
+      phase1(IC(1), IC(0), smem, smem);
+      if (is_edge(0)) mask_tile(IC(0), 0);
+      else asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+      phase2(IC(0), IC(0), smem, 0);
+      update(IC(0));
+    }
+
+    // ---- tiles this wave computes (two per trip: the score buffers alternate), then the tiles it only helps to
+    // move (other waves of the workgroup still need them: causal, this wave's rows end earlier)
+    auto land = [&]() {  // end of an iteration: this wave's share of tile t + 2 has landed (tile t + 3 may still fly)
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      __syncthreads();
+    };
+    unsigned long long st_sum[5] = {0, 0, 0, 0, 0};  // diagnostic build: cycles in phase 1 / mask / phase 2 / update / land
+    auto iter = [&](int t, auto CB_) {
+      constexpr int cb = decltype(CB_)::value;
+      unsigned long long c1 = 0, c2 = 0, c2b = 0, c3 = 0, c4 = 0, c5 = 0;
+      if constexpr (STAMP) c1 = __builtin_amdgcn_s_memtime();
+      const char* kb_n = smem + ((t + 1) & 3) * SM::STAGE;
+      const char* vb_c = smem + (t & 3) * SM::STAGE + SM::K_BYTES;
+      const bool has_next = (t + 1 < n_w);
+      phase1(CB_, IC(1), kb_n, vb_c);
+      if constexpr (STAMP) c2 = __builtin_amdgcn_s_memtime();
+      if (has_next && is_edge(t + 1)) mask_tile(IC(cb ^ 1), (t + 1) * FA_BN);
+      asm volatile("s_nop 4" ::: "memory");  // P written by the vector ALU is read by asm MFMAs next
+      if constexpr (STAMP) c2b = __builtin_amdgcn_s_memtime();
+      dma_tile_base(t + 3);
+      phase2(IC(cb ^ 1), IC(1), vb_c, t + 3);
+      if constexpr (STAMP) c3 = __builtin_amdgcn_s_memtime();
+      if (has_next) update(IC(cb ^ 1));
+      if constexpr (STAMP) c4 = __builtin_amdgcn_s_memtime();
+      land();
+      if constexpr (STAMP) {
+        c5 = __builtin_amdgcn_s_memtime();
+        st_sum[0] += c2 - c1; st_sum[1] += c2b - c2; st_sum[2] += c3 - c2b; st_sum[3] += c4 - c3; st_sum[4] += c5 - c4;
+      }
+    };
+    int t = 0;
+    for (; t + 1 < n_w; t += 2) {
+      iter(t, IC(0));
+      iter(t + 1, IC(1));
+    }
+    if (t < n_w) {
+      iter(t, IC(0));
+      ++t;
+    }
+    for (; t < n_tiles; ++t) {  // tiles this wave only helps to move
+      stage_dma(t + 3);
+      land();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be writing LDS when the next pass starts / the wave ends
+
+    if constexpr (STAMP) {  // p.mask doubles as the stamp buffer: [block][wave][8] u64 (last pass wins)
+      if (lane == 0 && p.mask != nullptr) {
+        unsigned long long* d = (unsigned long long*)p.mask + ((size_t)blockIdx.x * 4 + wave) * 8;
+        d[0] = st_sum[0]; d[1] = st_sum[1]; d[2] = st_sum[2]; d[3] = st_sum[3]; d[4] = st_sum[4]; d[5] = n_w; d[6] = n_tiles;
+      }
+    }
+    // ---- epilogue
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMAs retired before the accumulator file is read
+    fa2_for<QT>([&](auto QTI) {
+      constexpr int qt = decltype(QTI)::value;
+      const float l_tot = Fa2AccIO<FA3_T_L + qt>::template read4<0>()[0];
+      const float inv = (l_tot > 0.f) ? fast_rcp(l_tot) : 0.f;
+      if (q_ok[qt]) {
+        if (p.lse != nullptr && h == 0) {
+          const float lse = (l_tot > 0.f) ? (m_i[qt] + fast_log2(l_tot)) * FA_LN2 : -INFINITY;
+          p.lse[((int64_t)b * p.H + head) * p.Sq + qrow[qt]] = lse;
+        }
+      }
+      T* op = (p.o != nullptr) ? ((T*)p.o + b * p.os_b + head * p.os_h + (int64_t)(q_ok[qt] ? qrow[qt] : 0) * p.os_s) : nullptr;
+      float* oa = (p.o_acc != nullptr)
+                      ? (p.o_acc + (((int64_t)b * p.Sq + (q_ok[qt] ? qrow[qt] : 0)) * p.H + head) * p.D)
+                      : nullptr;
+      fa2_for<DT_>([&](auto DTI) {
+        constexpr int dt = decltype(DTI)::value;
+        constexpr int k = FA3_T_O + qt * DT_ + dt;
+        const f32x4_t v[4] = {Fa2AccIO<k>::template read4<0>(), Fa2AccIO<k>::template read4<1>(),
+                              Fa2AccIO<k>::template read4<2>(), Fa2AccIO<k>::template read4<3>()};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = 32 * dt + 8 * g + 4 * h;
+          if (q_ok[qt] && d0 < p.D) {
+            const float x0 = v[g][0] * inv, x1 = v[g][1] * inv, x2 = v[g][2] * inv, x3 = v[g][3] * inv;
+            if (op != nullptr) {
+              u32x2_t w = {pack2<T>(x0, x1), pack2<T>(x2, x3)};
+              *(u32x2_t*)(op + d0) = w;
+            }
+            if (oa != nullptr) {
+              f32x4_t w = {x0, x1, x2, x3};
+              *(f32x4_t*)(oa + d0) = w;
+            }
+          }
+        }
+      });
+    });
+  }  // pass
+#undef IC
+}

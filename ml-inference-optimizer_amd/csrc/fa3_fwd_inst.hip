@@ -2,6 +2,9 @@
 #include <cstdlib>
 
 #include "fa3_fwd2_kernel.h"
+#if FA_D == 64
+#include "fa3_fwd3_kernel.h"
+#endif
 
 #if FA_TYPE_ID == 0
 using FaT = __bf16;
@@ -48,6 +51,32 @@ static int launch_two(FaDev p, hipStream_t stream) {
   return 0;
 }
 
+#if FA_D == 64
+// third structure (software-pipelined across KV tiles): head dim 64, no user mask
+template <bool CAUSAL>
+static int launch_three(FaDev p, hipStream_t stream) {
+  p.nqblk = (p.Sq + FA3_BM - 1) / FA3_BM;
+  p.qgrid = CAUSAL ? (p.nqblk + 1) / 2 : p.nqblk;
+  const int grid = p.qgrid * p.B * p.H;
+  const size_t smem = FA3_STAGES * FaSmem<64>::STAGE;
+  auto kern = fa3_fwd3_kernel<FaT, CAUSAL>;
+  if (const char* e = std::getenv("MIO_FA_DBG_PTR")) {  // diagnostic build with in-kernel phase stamps (tools/fa_stamps.py)
+    kern = fa3_fwd3_kernel<FaT, CAUSAL, true>;
+    p.mask = (const void*)std::strtoull(e, nullptr, 0);
+  }
+  static bool attr_set = false;
+  if (!attr_set || std::getenv("MIO_FA_DBG_PTR")) {
+    hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (ea != hipSuccess) return mio_fail(std::string("fa3_fwd3: hipFuncSetAttribute: ") + hipGetErrorString(ea));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("fa3_fwd3 launch: ") + hipGetErrorString(e));
+  return 0;
+}
+#endif
+
 static int fa_impl() {  // MIO_FA_IMPL=1 selects the first structure (two waves per SIMD) for A/B runs
   static const int v = [] {
     const char* e = std::getenv("MIO_FA_IMPL");
@@ -62,6 +91,12 @@ int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t
   // kernel wins at head_dim > 64 (D128 causal 754 vs 555 TFLOP/s, D80 590 vs 407) and for non-causal D64; the
   // two-waves-per-SIMD kernel stays ahead for causal D64 inside the model (0.48 vs 0.52 ms per layer).
   // MIO_FA_IMPL=1 / 2 forces one of them for A/B runs.
+#if FA_D == 64
+  // head dim 64 without a user mask: the software-pipelined kernel (causal 0.37 vs 0.44 ms, full 0.65 vs 0.79 ms at
+  // B8 S4096 H16); MIO_FA_IMPL=1 / 2 force the older structures
+  if ((fa_impl() == 3 || fa_impl() == 0) && mask_kind == MIO_MASK_NONE && p.Sq > 128)
+    return causal ? launch_three<true>(p, stream) : launch_three<false>(p, stream);
+#endif
   const bool two = (fa_impl() == 2) || (fa_impl() != 1 && (FA_D > 64 || !causal));
   if (mask_kind == MIO_MASK_NONE && two && p.Sq > 128)
     return causal ? launch_two<true>(p, stream) : launch_two<false>(p, stream);

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""In-kernel phase stamps of fa3_fwd3_kernel (MIO_FA_DBG_PTR + MIO_FA_IMPL=3): cycles per KV tile spent in the DMA
+issue, phase 1 (QK^T || exp), phase 2 (PV || max), the reference update and the wait + barrier."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ml-inference-optimizer_amd"))
+causal = (sys.argv[1] == "causal") if len(sys.argv) > 1 else False
+B, S, H, D = 8, 4096, 16, 64
+nblk = (S + 255) // 256
+grid = B * H * ((nblk + 1) // 2 if causal else nblk)
+dbg = torch.zeros(grid * 4 * 8, dtype=torch.int64, device="cuda")
+os.environ["MIO_FA_DBG_PTR"] = str(dbg.data_ptr())
+os.environ["MIO_FA_IMPL"] = "3"
+from mio import ops
+torch.manual_seed(0)
+q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+for _ in range(300):
+    ops.fa3_fwd(q, k, v, causal=causal)
+torch.cuda.synchronize()
+d = dbg.view(grid, 4, 8).cpu().double()
+nw = d[..., 5].clamp_min(1)
+names = ["phase1 QK||exp", "edge masks", "phase2 PV||max||dma", "update", "wait+barrier"]
+tot = 0
+for i, n in enumerate(names):
+    per = (d[..., i] / nw).mean().item()
+    tot += per
+    print(f"{n:16s} {per:8.0f} cycles per tile (per wave, mean over waves; tiles of the last pass)")
+print(f"{'sum':16s} {tot:8.0f}")
+for w in range(4):
+    print(f"  wave {w}: " + "  ".join(f"{(d[:, w, i] / nw[:, w]).mean().item():7.0f}" for i in range(5)), " n_w", nw[:, w].mean().item())
