@@ -3,20 +3,19 @@
 // fa3_fwd2_kernel (one wave per SIMD, 64 query rows per wave) runs each tile as QK^T -> softmax -> PV in sequence, so
 // the matrix core idles during the softmax and the vector ALU idles during the MFMAs: 2375 cycles per tile against
 // 1024 of MFMA work (tools/fa_ab.py, rocprofv3 SQ counters).  Here, per wave and tile t:
-//   phase 1   S(t+1) = K(t+1) . Q~^T      20 MFMAs   ||   P(t) = exp2(S(t))        64 v_exp + 32 v_cvt_pk
-//   phase 2   O^T += V(t)^T . P(t)^T      24 MFMAs   ||   row max of S(t+1)        32 v_max3 (+ masks on edge tiles)
+//   phase 1   S(t+1) = K(t+1) . Q^T                  16 MFMAs   ||   P(t) = exp2(S(t))                  64 v_exp + 32 v_cvt_pk
+//   phase 2   O^T += V(t)^T . P(t)^T, L += ones . P(t)^T  24 MFMAs   ||   S(t+1) := S(t+1)*c - ref, row max    64 v_fma + 32 v_max3, DMA issue
 // with S double-buffered in VGPRs.  What makes the two sides balance:
-//   * Q is pre-scaled by softmax_scale*log2(e) and the reference maximum is subtracted INSIDE the matrix core: one
-//     extra k-step per score tile multiplies a ones column on the K side (kone) with -reference on the Q side (qm),
-//     so the accumulators already hold the exp2 arguments (no v_fma per element);
-//   * row sums come from the matrix core too: L^T += ones(32x16) . P^T into a 32x32 accumulator whose registers all
-//     hold the row sum (no v_add per element);
-//   * every MFMA is an asm statement on asm-owned registers: O^T, L, Q~, qm, kone, ones live in the accumulator
-//     file (MFMA A/B operands may come from there), which leaves the 256 architectural VGPRs to S (128), P (32)
-//     and the K / V fragments -- and every phase is a fixed sequence of micro-steps (1 MFMA + its share of the
-//     vector work) pinned with sched_barrier(0).  (Compiler-visible "+a"/"a" operands were tried: accumulator
-//     tuples get copied at branch joins right behind an asm MFMA whose latency the compiler does not know -- lost
-//     updates -- and "a" inputs are re-copied from VGPRs before every use.)
+//   * the scale-and-subtract of tile t+1 (exp2 domain, against the CURRENT reference) and its row maximum ride in the
+//     vector slack of the PV phase, so the exp phase is exp + convert only;
+//   * row sums come from the matrix core: L^T += ones(32x16) . P^T into a 32x32 accumulator whose registers all hold
+//     the row sum (no v_add per element);
+//   * every MFMA is an asm statement on asm-owned registers: O^T, L, Q, ones live in the accumulator file (MFMA
+//     A/B operands may come from there), which leaves the 256 architectural VGPRs to S (128), P (32) and the K / V
+//     fragments -- and every phase is a fixed sequence of micro-steps (MFMA + its share of the vector work) pinned
+//     with sched_barrier(0).  (Compiler-visible "+a"/"a" operands were tried: accumulator tuples get copied at branch
+//     joins right behind an asm MFMA whose latency the compiler does not know -- lost updates -- and "a" inputs are
+//     re-copied from VGPRs before every use.)
 // The reference only moves when a row outgrows it by 2^FA_RESCALE_THR (flash_attention_kernels.py:276-298 is the
 // algorithm: online softmax with running max / sum; exp -> exp2).  K/V tiles go global -> LDS by DMA through a 4-stage
 // ring (K(t+1) and V(t) are read while tiles t+2 and t+3 are in flight: a tile has two iterations to land), one
@@ -28,10 +27,9 @@ constexpr int FA3_BM = 256;     // query rows per workgroup (4 waves x 64)
 constexpr int FA3_STAGES = 4;
 // Accumulator-file map (all asm-owned, at the TOP of the file: the allocator hands out a0, a1, ... for its own
 // values first; tools/check_agpr.py verifies after every build that no compiler-generated instruction touches a112+):
-//   Q~ fragment (qt, ks) = a[112 + 16 qt + 4 ks : +3]      qm[qt] = a[144 + 4 qt : +3]  (-reference at k = 0)
-//   kone = a[152:155] (A operand, ones at k = 0)            ones = a[156:159] (A operand, all ones)
+//   Q fragment (qt, ks) = a[112 + 16 qt + 4 ks : +3]       ones = a[156:159] (A operand, all ones)
 //   O^T tile qt*2+dt = Fa2Acc tile 10 + qt*2+dt = a[160:223]   L tile qt = Fa2Acc tile 14 + qt = a[224:255]
-constexpr int FA3_A_Q = 112, FA3_A_QM = 144, FA3_T_O = 10, FA3_T_L = 14;
+constexpr int FA3_A_Q = 112, FA3_T_O = 10, FA3_T_L = 14;
 
 template <int R>
 struct Fa3AW;  // write one accumulator register (the clobber makes the register part of the kernel's allocation)
@@ -98,15 +96,13 @@ struct Fa3Ops;
   template <>                                                                                                         \
   struct Fa3Ops<TY> {                                                                                                 \
     using X8 = typename DT<TY>::x8;                                                                                   \
-    /* S += K fragment (VGPR) . Q~ fragment a[R:R+3] */                                                               \
-    template <int R>                                                                                                  \
+    /* S (+)= K fragment (VGPR) . Q fragment a[R:R+3]; FIRST: S = ... (C = 0) */                                     \
+    template <int R, bool FIRST>                                                                                      \
     static __device__ __forceinline__ void qk(f32x16_t& acc, const X8& kf) {                                          \
-      asm volatile("v_mfma_f32_32x32x16_" SUF " %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(kf), "n"(R), "n"(R + 3));     \
-    }                                                                                                                 \
-    /* S = kone . qm fragment a[R:R+3]  (= -reference in every score of the row) */                                   \
-    template <int R>                                                                                                  \
-    static __device__ __forceinline__ void qk_ref(f32x16_t& acc) {                                                    \
-      asm volatile("v_mfma_f32_32x32x16_" SUF " %0, a[152:155], a[%1:%2], 0" : "=v"(acc) : "n"(R), "n"(R + 3));       \
+      if constexpr (FIRST)                                                                                            \
+        asm volatile("v_mfma_f32_32x32x16_" SUF " %0, %1, a[%2:%3], 0" : "=v"(acc) : "v"(kf), "n"(R), "n"(R + 3));    \
+      else                                                                                                            \
+        asm volatile("v_mfma_f32_32x32x16_" SUF " %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(kf), "n"(R), "n"(R + 3));   \
     }                                                                                                                 \
     static __device__ __forceinline__ void lsum0(const X8& pf) {                                                      \
       asm volatile("v_mfma_f32_32x32x16_" SUF " a[224:239], a[156:159], %0, a[224:239]"                               \
@@ -158,14 +154,12 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
   const int b = bh / p.H, head = bh % p.H;
   const int kvh = head / (p.H / p.Hkv);
 
-  // constant MFMA operands: kone = A operand with ones at k = 0, ones = A operand of all ones; qm registers 1..3 = 0
+  // constant MFMA operand: ones = A operand of all ones (row sums)
   {
-    const uint32_t o2 = pack2<T>(1.f, 1.f), o1 = pack2<T>(h == 0 ? 1.f : 0.f, 0.f);
-    Fa3AW<152>::w(o1); Fa3AW<153>::w(0u); Fa3AW<154>::w(0u); Fa3AW<155>::w(0u);
+    const uint32_t o2 = pack2<T>(1.f, 1.f);
     Fa3AW<156>::w(o2); Fa3AW<157>::w(o2); Fa3AW<158>::w(o2); Fa3AW<159>::w(o2);
-    Fa3AW<145>::w(0u); Fa3AW<146>::w(0u); Fa3AW<147>::w(0u);
-    Fa3AW<149>::w(0u); Fa3AW<150>::w(0u); Fa3AW<151>::w(0u);
   }
+  const float c2 = p.scale_log2e;
 
   // per-lane LDS read offsets (layouts: fa3_fwd_kernel.h)
   const int k_rd = r * SM::KROW + 16 * h;
@@ -187,46 +181,34 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       q_ok[qt] = qrow[qt] < p.Sq;
     }
 
-    // ---- Q~ = Q * softmax_scale * log2(e) as MFMA B fragments (lane (r,h) holds Q~[row][16ks + 8h .. +7])
+    // ---- Q as MFMA B fragments in the accumulator file (lane (r,h) holds Q[row][16ks + 8h .. +7])
     fa2_for<QT * KS>([&](auto QK_) {
       constexpr int qt = decltype(QK_)::value / KS, ks = decltype(QK_)::value % KS;
       const T* qp = (const T*)p.q + b * p.qs_b + head * p.qs_h + (int64_t)(q_ok[qt] ? qrow[qt] : 0) * p.qs_s;
       const int d0 = 16 * ks + 8 * h;
       u32x4_t raw = *(const u32x4_t*)(qp + (d0 < p.D ? d0 : 0));
       if (!(q_ok[qt] && d0 < p.D)) raw = (u32x4_t){0, 0, 0, 0};
-      const X8 q8 = __builtin_bit_cast(X8, raw);
       constexpr int R = FA3_A_Q + 16 * qt + 4 * ks;
-      Fa3AW<R + 0>::w(pack2<T>((float)q8[0] * p.scale_log2e, (float)q8[1] * p.scale_log2e));
-      Fa3AW<R + 1>::w(pack2<T>((float)q8[2] * p.scale_log2e, (float)q8[3] * p.scale_log2e));
-      Fa3AW<R + 2>::w(pack2<T>((float)q8[4] * p.scale_log2e, (float)q8[5] * p.scale_log2e));
-      Fa3AW<R + 3>::w(pack2<T>((float)q8[6] * p.scale_log2e, (float)q8[7] * p.scale_log2e));
+      Fa3AW<R + 0>::w(raw[0]); Fa3AW<R + 1>::w(raw[1]); Fa3AW<R + 2>::w(raw[2]); Fa3AW<R + 3>::w(raw[3]);
     });
 
-    // ---- running state per query sub-tile: m_i = reference (exp2 domain, a value of type T so that it is exact as
-    // an MFMA operand; -inf = no finite score yet, the reference is then 0); qm = B fragment with -reference at k = 0;
-    // O^T tile qt*2+dt and the row-sum tile L[qt] (every register of a lane = the row sum)
-    float m_i[QT], lcarry[QT], rcarry[QT];
-    auto set_ref = [&](auto QTI, float ref) {
-      Fa3AW<FA3_A_QM + 4 * decltype(QTI)::value>::w(pack2<T>(h == 0 ? -ref : 0.f, 0.f));
-    };
+    // ---- running state per query sub-tile: m_i = reference the probabilities are taken against (exp2 domain; -inf =
+    // no finite score yet, the reference is then 0), negref = -reference as used by the scale-and-subtract
+    float m_i[QT], negref[QT], lcarry[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       m_i[qt] = -INFINITY;
-      float l0 = 0.f, ref0 = 0.f;
+      negref[qt] = 0.f;
+      lcarry[qt] = 0.f;
       if (p.carry_in && q_ok[qt]) {
         const float lse_in = p.lse[((int64_t)b * p.H + head) * p.Sq + qrow[qt]];
-        if (lse_in != -INFINITY) {  // carried state relative to a T-representable reference: l = 2^(lse - reference)
-          const float lse2 = lse_in * FA_LOG2E;
-          m_i[qt] = (float)(T)lse2;
-          l0 = fast_exp2(lse2 - m_i[qt]);
-          ref0 = m_i[qt];
+        if (lse_in != -INFINITY) {
+          m_i[qt] = lse_in * FA_LOG2E;
+          negref[qt] = -m_i[qt];
+          lcarry[qt] = 1.f;
         }
       }
-      lcarry[qt] = l0;
-      rcarry[qt] = ref0;
     }
-    set_ref(IC(0), rcarry[0]);
-    set_ref(IC(1), rcarry[1]);
     fa2_for<QT>([&](auto QTI) {
       constexpr int qt = decltype(QTI)::value;
       const f32x4_t lv = {lcarry[qt], lcarry[qt], lcarry[qt], lcarry[qt]};
@@ -378,10 +360,10 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       }
     };
 
-    // ---- phase 1: S[cb ^ 1] = scores of the next tile (K at kb)  ||  P = exp2(S[cb])  (+ the first V fragments from vb).
-    // The QK^T half always runs (after the last tile of the wave it produces scores nobody reads): a run-time
-    // "has next" would put the shared vector half under two branches, and the compiler then hoists it out of the
-    // pinned micro-steps.
+    // ---- phase 1: S[cb ^ 1] = RAW scores of the next tile (K at kb)  ||  P = exp2(S[cb]), row sums of P on the matrix
+    // core as soon as a fragment is complete (+ the first V fragments from vb).  The QK^T half always runs (after the
+    // last tile of the wave it produces scores nobody reads): a run-time "has next" would put the shared vector half
+    // under two branches, and the compiler then hoists it out of the pinned micro-steps.
     auto phase1 = [&](auto CB_, auto DO_EXP_, const char* kb, const char* vb) {
       constexpr int cb = decltype(CB_)::value, nb = cb ^ 1;
       constexpr bool DO_EXP = decltype(DO_EXP_)::value != 0;
@@ -395,30 +377,30 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       read_k(IC(1));
       auto step = [&](auto J_) {
         constexpr int j = decltype(J_)::value;
-        if constexpr (j < 4) {
-          OPS::template qk_ref<FA3_A_QM + 4 * (j >> 1)>(S[nb][j >> 1][j & 1]);
-        } else {
-          constexpr int ks = (j - 4) >> 2, qt = ((j - 4) & 3) >> 1, tt = (j - 4) & 1;
-          OPS::template qk<FA3_A_Q + 16 * qt + 4 * ks>(S[nb][qt][tt], kf[ks & 1][tt]);
+        if constexpr (j < 16) {
+          constexpr int ks = j >> 2, qt = (j & 3) >> 1, tt = j & 1;
+          OPS::template qk<FA3_A_Q + 16 * qt + 4 * ks, ks == 0>(S[nb][qt][tt], kf[ks & 1][tt]);
+          if constexpr (j == 3) read_k(IC(2));
+          if constexpr (j == 7) read_k(IC(3));
         }
-        if constexpr (j == 7) read_k(IC(2));
-        if constexpr (j == 11) read_k(IC(3));
-        if constexpr (DO_EXP && j >= 2 && j < 18) {
-          constexpr int i = j - 2, u = i >> 1, half = i & 1, qt = u >> 2, s = u & 3;
-          constexpr int base = 8 * (s & 1) + 4 * half;
-          const float e0 = fast_exp2(S[cb][qt][s >> 1][base + 0]);
-          const float e1 = fast_exp2(S[cb][qt][s >> 1][base + 1]);
-          const float e2 = fast_exp2(S[cb][qt][s >> 1][base + 2]);
-          const float e3 = fast_exp2(S[cb][qt][s >> 1][base + 3]);
-          const uint32_t w0 = pack2<T>(e0, e1), w1 = pack2<T>(e2, e3);
-          asm volatile("" ::"v"(w0), "v"(w1));  // a use in THIS block: keeps the exp / cvt work from sinking to phase 2
-          pfw[qt][s][2 * half + 0] = w0;
-          pfw[qt][s][2 * half + 1] = w1;
+        if constexpr (DO_EXP) {
+          if constexpr (j < 16) {
+            constexpr int u = j >> 1, half = j & 1, qt = u >> 2, s = u & 3;
+            constexpr int base = 8 * (s & 1) + 4 * half;
+            const float e0 = fast_exp2(S[cb][qt][s >> 1][base + 0]);
+            const float e1 = fast_exp2(S[cb][qt][s >> 1][base + 1]);
+            const float e2 = fast_exp2(S[cb][qt][s >> 1][base + 2]);
+            const float e3 = fast_exp2(S[cb][qt][s >> 1][base + 3]);
+            const uint32_t w0 = pack2<T>(e0, e1), w1 = pack2<T>(e2, e3);
+            asm volatile("" ::"v"(w0), "v"(w1));  // a use in THIS block: keeps the exp / cvt work from sinking to phase 2
+            pfw[qt][s][2 * half + 0] = w0;
+            pfw[qt][s][2 * half + 1] = w1;
+          }
+          if constexpr (j == 15) read_v(vb, IC(0));
         }
-        if constexpr (DO_EXP && j == 17) read_v(vb, IC(0));
         __builtin_amdgcn_sched_barrier(0);
       };
-      fa2_for<20>(step);
+      fa2_for<16>(step);
     };
 
     // ---- masks of an edge tile (causal diagonal, keys past Sk) on S[nb]; first key kv0n.  Rare: not overlapped.
@@ -443,12 +425,13 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       });
     };
 
-    // ---- phase 2: O^T += V^T . P^T, L += ones . P^T   ||   row max of S[nb] (the next tile)
+    // ---- phase 2: O^T += V^T . P^T, L += ones . P^T   ||   S[nb] := S[nb] * c2 - reference (exp2 domain) and its
+    // row max, DMA issue
     auto phase2 = [&](auto NB_, auto DO_PV_, const char* vb, int dma_tile) {
       constexpr int nb = decltype(NB_)::value;
       constexpr bool DO_PV = decltype(DO_PV_)::value != 0;
       auto step = [&](auto J_) {
-        constexpr int j = decltype(J_)::value;
+        constexpr int j = decltype(J_)::value;  // 24 steps: k-step s = j / 6, MFMA m = j % 6
         constexpr int s = j / 6, m = j % 6;
         if constexpr (DO_PV) {
           if constexpr (m < 4) {
@@ -462,17 +445,28 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
           if constexpr (m == 1 && s + 1 < 4) read_v(vb, IC(s + 1));  // slot (s+1)&1 was last read by k-step s-1
           if constexpr (j % 5 == 3 && j / 5 < 5) dma_unit(IC(j / 5), dma_tile);  // steps 3, 8, 13, 18, 23: tile t + 3
         }
-        if constexpr (j >= 4 && j < 20) {
-          constexpr int k = j - 4;  // 16 steps: three, then two more values per step
-#pragma unroll
-          for (int qt = 0; qt < QT; ++qt) {
-            // element e of the 32 scores of this lane: tile e >> 4, register e & 15
-            auto val = [&](int e) { return S[nb][qt][e >> 4][e & 15]; };
-            if constexpr (k == 0) mx[qt] = fmaxf(fmaxf(val(0), val(1)), val(2));
-            else if constexpr (k == 15) mx[qt] = fmaxf(mx[qt], val(31));
-            else mx[qt] = fmaxf(fmaxf(mx[qt], val(2 * k + 1)), val(2 * k + 2));
-            asm volatile("" : "+v"(mx[qt]));  // pins this step's share of the max chain to this micro-step
-          }
+        // scale-and-subtract + max of 4 scores per step (steps 2..17), in the order the QK^T MFMAs of phase 1 finished
+        // writing them: sub-tile qt = i / 8, 32-key half tt = (i / 4) & 1, registers 4 (i & 3) .. +3
+        if constexpr (j >= 2 && j < 18) {
+          constexpr int i = j - 2, qt = i / 8, tt = (i / 4) & 1, r0 = 4 * (i & 3);
+          // single-instruction fmas: left to the compiler, adjacent scalar fmas are SLP-packed into v_pk_fma_f32, which
+          // costs more issue time beside MFMAs than the two scalar forms (MI355X_MICROARCH.md, packed f32 VALU)
+          auto fma1 = [&](float x) {
+            float d;
+            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(c2), "v"(negref[qt]));
+            return d;
+          };
+          float v0 = fma1(S[nb][qt][tt][r0 + 0]);
+          float v1 = fma1(S[nb][qt][tt][r0 + 1]);
+          float v2 = fma1(S[nb][qt][tt][r0 + 2]);
+          float v3 = fma1(S[nb][qt][tt][r0 + 3]);
+          S[nb][qt][tt][r0 + 0] = v0;
+          S[nb][qt][tt][r0 + 1] = v1;
+          S[nb][qt][tt][r0 + 2] = v2;
+          S[nb][qt][tt][r0 + 3] = v3;
+          if constexpr ((i & 7) == 0) mx[qt] = fmaxf(fmaxf(fmaxf(v0, v1), v2), v3);
+          else mx[qt] = fmaxf(fmaxf(fmaxf(fmaxf(mx[qt], v0), v1), v2), v3);  // two v_max3
+          asm volatile("" : "+v"(mx[qt]));  // pins this step's share of the work to this micro-step
         }
         __builtin_amdgcn_sched_barrier(0);
       };
@@ -483,17 +477,18 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
     // wave-uniform test for both query sub-tiles; inside, a row that does not need to move gets delta = 0, alpha = 1.
     auto update = [&](auto NB_) {
       constexpr int nb = decltype(NB_)::value;
-      float mxr[QT];
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) mxr[qt] = fmaxf(mx[qt], other_half(mx[qt]));
-      const bool trig = (mxr[0] > FA_RESCALE_THR) || (m_i[0] == -INFINITY) || (mxr[1] > FA_RESCALE_THR) || (m_i[1] == -INFINITY);
+      // per-lane test on the half-row maxima (the two lane halves of a row are only combined inside the rare branch)
+      const bool trig = (mx[0] > FA_RESCALE_THR) || (m_i[0] == -INFINITY) || (mx[1] > FA_RESCALE_THR) || (m_i[1] == -INFINITY);
       if (__builtin_amdgcn_ballot_w64(trig) != 0) {
+        float mxr[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mxr[qt] = fmaxf(mx[qt], other_half(mx[qt]));
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs retired before the file is read
         fa2_for<QT>([&](auto QTI) {
           constexpr int qt = decltype(QTI)::value;
           const bool fresh = (m_i[qt] == -INFINITY);
           const float ref_old = fresh ? 0.f : m_i[qt];
-          const float m_new = (float)(T)fmaxf(m_i[qt], mxr[qt] + ref_old);  // the reference must be exact as a T operand
+          const float m_new = fmaxf(m_i[qt], mxr[qt] + ref_old);
           const float ref_new = (m_new == -INFINITY) ? 0.f : m_new;
           const float delta = ref_new - ref_old;
           const float alpha = fresh ? 1.f : fast_exp2(-delta);
@@ -519,7 +514,7 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
           rescale(IC(FA3_T_O + qt * DT_ + 0));
           rescale(IC(FA3_T_O + qt * DT_ + 1));
           rescale(IC(FA3_T_L + qt));
-          set_ref(QTI, ref_new);
+          negref[qt] = -ref_new;
         });
         asm volatile("s_nop 7" ::: "memory");
       }
@@ -551,7 +546,7 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       phase1(CB_, IC(1), kb_n, vb_c);
       if constexpr (STAMP) c2 = __builtin_amdgcn_s_memtime();
       if (has_next && is_edge(t + 1)) mask_tile(IC(cb ^ 1), (t + 1) * FA_BN);
-      asm volatile("s_nop 4" ::: "memory");  // P written by the vector ALU is read by asm MFMAs next
+      // (P words written by the vector ALU late in phase 1 are first read by an MFMA many steps into phase 2)
       if constexpr (STAMP) c2b = __builtin_amdgcn_s_memtime();
       dma_tile_base(t + 3);
       phase2(IC(cb ^ 1), IC(1), vb_c, t + 3);
