@@ -14,19 +14,32 @@ src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
 
+ACT = {"0": "none", "1": "gelu_tanh", "2": "gelu_erf", "3": "relu", "4": "silu", "5": "swiglu"}
+
+
 def short(name):
-    m = re.match(r"(?:void )?(\w+)<(.*)>\(", name) or re.match(r"(?:void )?(\w+)<(.*)>", name)
-    if not m:
-        return name[:60]
-    k, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
-    dt = {"__bf16": "bf16", "_Float16": "fp16", "__hip_bfloat16": "bf16"}.get(args[0], args[0])
-    if k in ("gemm4w16_kernel", "gemm4w16p_kernel", "gemm_bias_act_kernel"):
-        act = {"0": "none", "1": "gelu_tanh", "2": "gelu_erf", "3": "relu", "4": "silu", "5": "swiglu"}
-        i = 1 if k != "gemm_bias_act_kernel" else len(args) - 1
-        return f"{k}<{dt},{act.get(args[i], args[i])}>"
-    if k in ("fa3_fwd_kernel", "fa3_fwd2_kernel"):
-        return f"{k}<{dt},D{args[1]},{'causal' if args[2] in ('true', '1') else 'full'}>"
-    return f"{k}<{dt}>"
+    """Kernel symbol (Itanium-mangled, or rocprofv3's partly demangled form) -> the short name bench.py uses."""
+    m = re.match(r"_Z\d+(\w+?_kernel)I(.*)E+v", name)
+    if m:  # mangled: template args DF16b = __bf16, DF16_ = _Float16, Li<N>E = int, Lb<0|1>E = bool
+        k, rest = m.group(1), m.group(2)
+        dt = "bf16" if rest.startswith("DF16b") else ("fp16" if rest.startswith("DF16_") else "?")
+        ints = re.findall(r"L([ib])(\d+)E", rest)
+        vals = [v for _, v in ints]
+        if k in ("gemm4w16_kernel", "gemm4w16p_kernel"):
+            return f"{k}<{dt},{ACT.get(vals[0], vals[0])}>"
+        if k == "gemm_bias_act_kernel":
+            return f"{k}<{dt},{ACT.get(vals[-1], vals[-1])}>"
+        if k in ("fa3_fwd_kernel", "fa3_fwd2_kernel"):
+            return f"{k}<{dt},D{vals[0]},{'causal' if vals[1] == '1' else 'full'}>"
+        if k == "fa3_fwd3_kernel":
+            return f"{k}<{dt},{'causal' if vals[0] == '1' else 'full'}>"
+        return f"{k}<{dt}>"
+    if re.match(r"(?:void )?fa3_fwd3_kernel<bool _Accum, bool, E", name):  # <__bf16, true, false> mis-demangled
+        return "fa3_fwd3_kernel<bf16,causal>"
+    m = re.match(r"(?:void )?(\w+_kernel)<bool _Accum, int, E(?:, (\d+))?", name)
+    if m:  # rocprofv3 mis-demangles <__bf16, 1, ...>: only the gelu_tanh (ACT = 1) GEMMs of the benchmark show up so
+        return f"{m.group(1)}<bf16,gelu_tanh>"
+    return name[:60]
 
 
 def counter_means(path):
