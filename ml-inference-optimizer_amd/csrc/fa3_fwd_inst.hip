@@ -77,7 +77,7 @@ static int launch_three(FaDev p, hipStream_t stream) {
 }
 #endif
 
-static int fa_impl() {  // MIO_FA_IMPL=1 selects the first structure (two waves per SIMD) for A/B runs
+static int fa_impl() {  // MIO_FA_IMPL=1 / 2 / 3 force one structure for A/B runs (0 = the rule in fa3_launch)
   static const int v = [] {
     const char* e = std::getenv("MIO_FA_IMPL");
     return e ? std::atoi(e) : 0;
@@ -87,13 +87,13 @@ static int fa_impl() {  // MIO_FA_IMPL=1 selects the first structure (two waves 
 
 template <>
 int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t stream) {
-  // Structure choice (measured on MI355X, B8 S4096 H16, random data): the one-wave-per-SIMD / 64-rows-per-wave
-  // kernel wins at head_dim > 64 (D128 causal 754 vs 555 TFLOP/s, D80 590 vs 407) and for non-causal D64; the
-  // two-waves-per-SIMD kernel stays ahead for causal D64 inside the model (0.48 vs 0.52 ms per layer).
-  // MIO_FA_IMPL=1 / 2 forces one of them for A/B runs.
+  // Structure choice (measured on MI355X, B8 S4096 H16, random data; MIO_FA_IMPL=1 / 2 / 3 forces one for A/B runs):
+  //   head dim 64, no user mask: the software-pipelined kernel (causal 0.359 ms vs 0.442 for the two-waves-per-SIMD
+  //     kernel and 0.52 for the sequential one-wave kernel; non-causal 0.626 vs 0.79);
+  //   head dim 96 / 128, no user mask: the one-wave-per-SIMD / 64-rows-per-wave kernel (D128 causal 760 vs 555 TFLOP/s,
+  //     D80 595 vs 407);
+  //   user masks and Sq <= 128: the two-waves-per-SIMD kernel.
 #if FA_D == 64
-  // head dim 64 without a user mask: the software-pipelined kernel (causal 0.37 vs 0.44 ms, full 0.65 vs 0.79 ms at
-  // B8 S4096 H16); MIO_FA_IMPL=1 / 2 force the older structures
   if ((fa_impl() == 3 || fa_impl() == 0) && mask_kind == MIO_MASK_NONE && p.Sq > 128)
     return causal ? launch_three<true>(p, stream) : launch_three<false>(p, stream);
 #endif
