@@ -8,9 +8,10 @@ bf16, causal FA3 + FusedMLP) on N MI355X, plus the roofline of the dominant kern
 
 One "step" = one forward of the whole stack over one synthetic batch resident in HBM.  tokens/s =
 B*S / avg latency (reference benchmarks/runners.py:356-358).  N > 1: one process per GPU, the batch
-dimension is sharded (independent sequences, no data-path collective) -> weak scaling; the
-tensor-parallel (config 3) and ring-attention (config 4) exchange paths are measured after the timed
-region and reported under "extra" (they are strong-scaling measurements of the same global work).
+dimension is sharded (independent sequences, no data-path collective) -> weak scaling.  With --parallel-extras
+the tensor-parallel (config 3) and ring-attention (config 4) exchange paths are also measured after the timed
+region and reported under "extra" (strong-scaling measurements of the same global work); they are opt-in because
+a collective that hangs there would take the headline line down with it.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -122,7 +123,9 @@ def main():
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--heads", type=int, default=16)
     ap.add_argument("--layers", type=int, default=24)
-    ap.add_argument("--no-extra", action="store_true", help="skip roofline / cpu baseline / tp / ring extras")
+    ap.add_argument("--no-extra", action="store_true", help="skip the roofline / cpu-baseline legs (N = 1)")
+    ap.add_argument("--parallel-extras", action="store_true",
+                    help="N > 1: also time the tensor-parallel and ring-attention paths (RCCL collectives)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,8 +134,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MIO_BENCH_BACKEND", "nccl")  # "gloo": single-GPU rehearsal of the N > 1 plumbing
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     N = world
@@ -162,7 +170,7 @@ def main():
         sync_all()
         elapsed = time.perf_counter() - t0
     if N > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = elapsed / a.steps * 1e3
@@ -221,7 +229,7 @@ def main():
         except Exception as ex:
             res["cpu_baseline_error"] = repr(ex)
 
-    if not a.no_extra and N > 1:
+    if a.parallel_extras and N > 1:
         extra = {}
         try:
             from tools.bench_parallel import bench_tp, bench_ring
