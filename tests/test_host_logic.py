@@ -264,7 +264,8 @@ def test_ring_attention_config_and_shells():
         cross(torch.zeros(1, 4, 32), torch.zeros(1, 4, 32))
 
 
-def test_fwd3_accumulator_registers_untouched_by_compiler(tmp_path):
+@pytest.mark.parametrize("type_id", [0, 1])
+def test_fwd3_accumulator_registers_untouched_by_compiler(tmp_path, type_id):
     """fa3_fwd3_kernel keeps O^T, L, Q and the ones operand in accumulator registers a112..a255 that only its inline
     asm names.  The allocator does not know they are live between asm statements, so the build is only sound if no
     compiler-generated instruction touches them: check the ISA of every instantiation (tools/check_agpr.py)."""
@@ -276,7 +277,7 @@ def test_fwd3_accumulator_registers_untouched_by_compiler(tmp_path):
     csrc = os.path.join(ROOT, "ml-inference-optimizer_amd", "csrc")
     isa = tmp_path / "fa64.s"
     subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I../../include", "-I.", "-Wno-unused-value",
-                    "-mllvm", "-amdgpu-mfma-vgpr-form", "-DFA_TYPE_ID=0", "-DFA_D=64", "-S", "--cuda-device-only",
+                    "-mllvm", "-amdgpu-mfma-vgpr-form", f"-DFA_TYPE_ID={type_id}", "-DFA_D=64", "-S", "--cuda-device-only",
                     "fa3_fwd_inst.hip", "-o", str(isa)], cwd=csrc, check=True, capture_output=True)
     text = isa.read_text().splitlines()
     starts = [i for i, l in enumerate(text) if re.match(r"^_Z15fa3_fwd3_kernel\w+:", l)]
