@@ -21,7 +21,7 @@
 constexpr int FA2_QT = 2;             // 32-row query sub-tiles per wave
 constexpr int FA2_BM = 4 * 32 * FA2_QT;  // 256 query rows per workgroup
 
-// O^T accumulator tile k (16 registers) = a[16k : 16k+15], asm-owned (see gemm4w16_acc.inc for the pattern).
+// Accumulator tile k (16 registers) = a[16k : 16k+15], asm-owned (see gemm4w16_acc.inc for the pattern).
 template <typename T, int K>
 struct Fa2Acc;
 #define FA2_CL(B) "a" #B
@@ -97,8 +97,10 @@ FA2_DEF(4, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79)
 FA2_DEF(5, 80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 90, 91, 92, 93, 94, 95)
 FA2_DEF(6, 96, 97, 98, 99, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111)
 FA2_DEF(7, 112, 113, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124, 125, 126, 127)
-// tiles 10..15 = a[160:255]: the top of the accumulator file (fa3_fwd3_kernel.h keeps its accumulators there, out of
-// the way of the low registers the allocator hands out first)
+// tiles 8..15 = a[128:255]: the top of the accumulator file, where fa3_fwd2 / fa3_fwd3 keep their accumulators, out of
+// the way of the low registers the allocator hands out first
+FA2_DEF(8, 128, 129, 130, 131, 132, 133, 134, 135, 136, 137, 138, 139, 140, 141, 142, 143)
+FA2_DEF(9, 144, 145, 146, 147, 148, 149, 150, 151, 152, 153, 154, 155, 156, 157, 158, 159)
 FA2_DEF(10, 160, 161, 162, 163, 164, 165, 166, 167, 168, 169, 170, 171, 172, 173, 174, 175)
 FA2_DEF(11, 176, 177, 178, 179, 180, 181, 182, 183, 184, 185, 186, 187, 188, 189, 190, 191)
 FA2_DEF(12, 192, 193, 194, 195, 196, 197, 198, 199, 200, 201, 202, 203, 204, 205, 206, 207)
@@ -129,6 +131,11 @@ __global__ __launch_bounds__(256) void fa3_fwd2_kernel(const FaDev p) {
   constexpr int CPR = D / 8;
   constexpr int NLD = D / 32;
   static_assert(QT * DT_ <= 8, "accumulator tiles");
+  // The O^T tiles sit at the TOP of the accumulator file (tile KO + k): the allocator hands out a0, a1, ... first for
+  // its own values -- under VGPR pressure (D = 96 / 128) it parks temporaries there, including between two asm
+  // statements of the rare rescale path, where registers only protected by clobber lists look free to it.
+  // tests/test_host_logic.py checks after every build that no compiler-generated instruction touches the owned range.
+  constexpr int KO = 16 - QT * DT_;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -207,10 +214,10 @@ __global__ __launch_bounds__(256) void fa3_fwd2_kernel(const FaDev p) {
         if (d0 < p.D) z[g] = *(const f32x4_t*)(oa + d0);
       }
     }
-    Fa2AccIO<k>::template write4<0>(z[0]);
-    Fa2AccIO<k>::template write4<1>(z[1]);
-    Fa2AccIO<k>::template write4<2>(z[2]);
-    Fa2AccIO<k>::template write4<3>(z[3]);
+    Fa2AccIO<KO + k>::template write4<0>(z[0]);
+    Fa2AccIO<KO + k>::template write4<1>(z[1]);
+    Fa2AccIO<KO + k>::template write4<2>(z[2]);
+    Fa2AccIO<KO + k>::template write4<3>(z[3]);
   });
   if (p.carry_in) {
 #pragma unroll
@@ -370,16 +377,16 @@ __global__ __launch_bounds__(256) void fa3_fwd2_kernel(const FaDev p) {
         // rescale this sub-tile's O^T accumulators through the VALU (rare: deferred-rescale threshold)
         fa2_for<DT_>([&](auto DTI) {
           constexpr int k = qt * DT_ + decltype(DTI)::value;
-          f32x4_t v[4] = {Fa2AccIO<k>::template read4<0>(), Fa2AccIO<k>::template read4<1>(),
-                          Fa2AccIO<k>::template read4<2>(), Fa2AccIO<k>::template read4<3>()};
+          f32x4_t v[4] = {Fa2AccIO<KO + k>::template read4<0>(), Fa2AccIO<KO + k>::template read4<1>(),
+                          Fa2AccIO<KO + k>::template read4<2>(), Fa2AccIO<KO + k>::template read4<3>()};
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[gq][e] *= alpha;
-          Fa2AccIO<k>::template write4<0>(v[0]);
-          Fa2AccIO<k>::template write4<1>(v[1]);
-          Fa2AccIO<k>::template write4<2>(v[2]);
-          Fa2AccIO<k>::template write4<3>(v[3]);
+          Fa2AccIO<KO + k>::template write4<0>(v[0]);
+          Fa2AccIO<KO + k>::template write4<1>(v[1]);
+          Fa2AccIO<KO + k>::template write4<2>(v[2]);
+          Fa2AccIO<KO + k>::template write4<3>(v[3]);
         });
       } else {
         m_sub = m_i[qt];
@@ -414,8 +421,8 @@ __global__ __launch_bounds__(256) void fa3_fwd2_kernel(const FaDev p) {
     for (int s = 0; s < 4; ++s) {
       fa2_for<DT_>([&](auto DTI) {
         constexpr int dt = decltype(DTI)::value;
-        Fa2Acc<T, 0 * DT_ + dt>::mfma(vfr[s][dt], pf[0][s]);
-        Fa2Acc<T, 1 * DT_ + dt>::mfma(vfr[s][dt], pf[1][s]);
+        Fa2Acc<T, KO + 0 * DT_ + dt>::mfma(vfr[s][dt], pf[0][s]);
+        Fa2Acc<T, KO + 1 * DT_ + dt>::mfma(vfr[s][dt], pf[1][s]);
       });
     }
   };
@@ -457,8 +464,8 @@ __global__ __launch_bounds__(256) void fa3_fwd2_kernel(const FaDev p) {
     fa2_for<DT_>([&](auto DTI) {
       constexpr int dt = decltype(DTI)::value;
       constexpr int k = qt * DT_ + dt;
-      const f32x4_t v[4] = {Fa2AccIO<k>::template read4<0>(), Fa2AccIO<k>::template read4<1>(),
-                            Fa2AccIO<k>::template read4<2>(), Fa2AccIO<k>::template read4<3>()};
+      const f32x4_t v[4] = {Fa2AccIO<KO + k>::template read4<0>(), Fa2AccIO<KO + k>::template read4<1>(),
+                            Fa2AccIO<KO + k>::template read4<2>(), Fa2AccIO<KO + k>::template read4<3>()};
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d0 = 32 * dt + 8 * g + 4 * h;

@@ -64,15 +64,17 @@ def test_fa3_fwd_vs_oracle(dtype, B, Sq, Sk, H, Hkv, D, causal):
 
 @pytest.mark.parametrize("causal", [True, False])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_fa3_benchmark_length(dtype, causal):
+@pytest.mark.parametrize("D,S,H", [(64, 4096, 8), (128, 2048, 4), (80, 1536, 4)])
+def test_fa3_benchmark_length(dtype, causal, D, S, H):
     """Sequence length of the benchmark (4096 = 64 KV tiles per query block: many reference moves, the 4-stage DMA
     ring wraps 16 times, heavy + light causal passes) with head dim 64 -> the software-pipelined kernel.  The CPU oracle
     cannot finish this size in seconds, so the checker is plain fp32 torch on the GPU (softmax(q k^T / sqrt(D)) v) on
     the same 16-bit inputs; lse against logsumexp.  Scores are scaled up (q * 3) so that rows really outgrow their
-    running reference by more than the rescale threshold several times."""
+    running reference by more than the rescale threshold several times (the rare path that rescales the asm-owned
+    accumulators).  Head dims 128 and 80 take the one-wave-per-SIMD kernel (fa3_fwd2)."""
     ops = _ops()
     torch.manual_seed(17)
-    B, S, H, D = 1, 4096, 8, 64
+    B = 1
     q = (torch.randn(B, S, H, D, device=DEV) * 3).to(dtype)
     k = torch.randn(B, S, H, D, device=DEV).to(dtype)
     v = torch.randn(B, S, H, D, device=DEV).to(dtype)

@@ -290,3 +290,57 @@ def test_fwd3_accumulator_registers_untouched_by_compiler(tmp_path, type_id):
                            capture_output=True, text=True)
         assert r.returncode == 0, text[a] + "\n" + r.stdout
         assert not any("scratch_" in l for l in text[a:b + 1]), "register spills in " + text[a]
+
+
+@pytest.mark.parametrize("D", [64, 96, 128])
+def test_fwd2_accumulator_registers_untouched_by_compiler(tmp_path, D):
+    """fa3_fwd2_kernel keeps its 2*D/32 O^T tiles in the top accumulator registers a[256 - 32*D/32*... : 255] through
+    inline asm only; same soundness condition as for fwd3 (a version with the tiles at a0.. had the compiler park
+    temporaries in a0-a2 inside the rescale path at D = 96 / 128)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "ml-inference-optimizer_amd", "csrc")
+    isa = tmp_path / "fa.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I../../include", "-I.", "-Wno-unused-value",
+                    "-mllvm", "-amdgpu-mfma-vgpr-form", "-DFA_TYPE_ID=0", f"-DFA_D={D}", "-S", "--cuda-device-only",
+                    "fa3_fwd_inst.hip", "-o", str(isa)], cwd=csrc, check=True, capture_output=True)
+    text = isa.read_text().splitlines()
+    starts = [i for i, l in enumerate(text) if re.match(r"^_Z15fa3_fwd2_kernel\w+:", l)]
+    assert len(starts) == 2
+    floor = 256 - 16 * (2 * D // 32)
+    for a in starts:
+        b = next(i for i in range(a, len(text)) if "s_endpgm" in text[i])
+        part = tmp_path / "k.s"
+        part.write_text("\n".join(text[a:b + 1]))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_agpr.py"), str(part), str(floor)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, text[a] + "\n" + r.stdout
+
+
+def test_gemm_accumulator_file_untouched_by_compiler(tmp_path):
+    """gemm4w16_kernel / gemm4w16p_kernel own the WHOLE accumulator file through inline asm: no compiler-generated
+    instruction may touch any accumulator register, and nothing may spill."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "ml-inference-optimizer_amd", "csrc")
+    isa = tmp_path / "gemm.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I../../include", "-I.", "-Wno-unused-value",
+                    "-DGEMM_TYPE_ID=0", "-S", "--cuda-device-only", "gemm_inst.hip", "-o", str(isa)],
+                   cwd=csrc, check=True, capture_output=True)
+    text = isa.read_text().splitlines()
+    starts = [i for i, l in enumerate(text) if re.match(r"^_Z1[56]gemm4w16p?_kernel\w+:", l)]
+    assert len(starts) >= 10
+    for a in starts:
+        b = next(i for i in range(a, len(text)) if "s_endpgm" in text[i])
+        part = tmp_path / "k.s"
+        part.write_text("\n".join(text[a:b + 1]))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_agpr.py"), str(part), "0"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, text[a] + "\n" + r.stdout
+        assert not any("scratch_" in l for l in text[a:b + 1]), "register spills in " + text[a]
