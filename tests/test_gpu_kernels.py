@@ -247,7 +247,8 @@ def test_gemm_edges_and_residual(dtype):
 @pytest.mark.parametrize("M,N,K,act,res", [
     (4096 + 37, 4096 + 8, 1024, "none", False),   # persistent kernel, 1 store / K-tile, ragged M and N, 289 tiles
     (8192, 2304 + 24, 256, "gelu", False),        # persistent, 4 stores / K-tile, 320 tiles
-    (5000, 3584, 544, "silu", False),             # persistent, 2 stores / K-tile, odd number of K-tiles
+    (5000, 3584, 544, "silu", False),             # K % 64 != 0 -> one-tile kernel
+    (4096 + 5, 4096, 512, "gelu_erf", False),     # persistent, 2 stores / K-tile, erf read-out
     (4352, 4096, 288, "none", True),              # residual epilogue -> one-tile-per-workgroup 256x256 kernel
     (4352 + 3, 4096, 264, "relu", True),          # K % 32 != 0 -> generic 256x256 kernel
 ])
@@ -265,7 +266,8 @@ def test_gemm_big_tiles(dtype, M, N, K, act, res):
     y = ops.gemm_bias_act(x.to(DEV), w.to(DEV), b.to(DEV), act, residual=None if r is None else r.to(DEV))
     from oracle.mlp import gelu_tanh
     z = (x.float() @ w.float().T).double() + b.double()
-    z = {"none": lambda t: t, "gelu": gelu_tanh, "relu": torch.relu, "silu": torch.nn.functional.silu}[act](z)
+    z = {"none": lambda t: t, "gelu": gelu_tanh, "gelu_erf": torch.nn.functional.gelu, "relu": torch.relu,
+         "silu": torch.nn.functional.silu}[act](z)
     if r is not None:
         z = z + r.double()
     _cmp(y, z, dtype, f"gemm {M}x{N}x{K} {act} res={res}")
