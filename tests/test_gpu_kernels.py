@@ -62,6 +62,36 @@ def test_fa3_fwd_vs_oracle(dtype, B, Sq, Sk, H, Hkv, D, causal):
     assert torch.equal(o2, o)
 
 
+@pytest.mark.parametrize("Sq,Sk,causal,q_off,k_off", [
+    (129, 1, False, 0, 0), (129, 63, False, 0, 0), (200, 64, False, 0, 0), (256, 65, False, 0, 0),
+    (257, 130, False, 0, 0), (511, 257, False, 0, 0), (300, 700, False, 0, 0),
+    (129, 129, True, 0, 0), (256, 256, True, 0, 0), (257, 257, True, 0, 0), (511, 511, True, 0, 0),
+    (200, 200, True, 200, 0),    # ring step: keys entirely in the past (nothing masked)
+    (200, 200, True, 0, 200),    # keys entirely in the future: every row empty (o = 0, lse = -inf)
+    (256, 192, True, 64, 128),   # partial overlap, unaligned offsets
+    (130, 300, True, 170, 0),    # queries are the tail of a longer sequence
+])
+def test_fa3_pipelined_kernel_shapes(Sq, Sk, causal, q_off, k_off):
+    """Edge shapes of the software-pipelined kernel (head dim 64, Sq > 128): one-tile and ragged KV, ragged query
+    blocks, waves with no visible key, causal diagonals at arbitrary offsets, grouped KV heads, B*H not a multiple
+    of 8 (no XCD remap)."""
+    ops = _ops()
+    torch.manual_seed(Sq * 7 + Sk)
+    dtype, B, H, Hkv, D = torch.float16, 1, 6, 2, 64
+    q = torch.randn(B, Sq, H, D, dtype=dtype)
+    k = torch.randn(B, Sk, Hkv, D, dtype=dtype)
+    v = torch.randn(B, Sk, Hkv, D, dtype=dtype)
+    o, lse = ops.fa3_fwd(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal, q_offset=q_off, k_offset=k_off, return_lse=True)
+    ref, rlse = oracle.attention_with_lse(q, k, v, causal=causal, q_offset=q_off, k_offset=k_off)
+    empty = torch.isinf(rlse)                       # rows without a visible key
+    assert torch.equal(torch.isinf(lse.cpu()), empty)
+    assert (lse.cpu().double() - rlse)[~empty].abs().max() < 2e-3 if (~empty).any() else True
+    keep = (~empty).permute(0, 2, 1)[..., None].expand_as(ref)   # [B,H,Sq] -> [B,Sq,H,D]
+    if keep.any():
+        _cmp(o.cpu()[keep], ref[keep], dtype, "o")
+    assert (o.cpu()[~keep] == 0).all()
+
+
 @pytest.mark.parametrize("causal", [True, False])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("D,S,H", [(64, 4096, 8), (128, 2048, 4), (80, 1536, 4)])
