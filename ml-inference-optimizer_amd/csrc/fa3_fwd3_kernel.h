@@ -26,10 +26,19 @@
 constexpr int FA3_BM = 256;     // query rows per workgroup (4 waves x 64)
 constexpr int FA3_STAGES = 4;
 // Accumulator-file map (all asm-owned, at the TOP of the file: the allocator hands out a0, a1, ... for its own
-// values first; tools/check_agpr.py verifies after every build that no compiler-generated instruction touches a112+):
-//   Q fragment (qt, ks) = a[112 + 16 qt + 4 ks : +3]       ones = a[156:159] (A operand, all ones)
-//   O^T tile qt*2+dt = Fa2Acc tile 10 + qt*2+dt = a[160:223]   L tile qt = Fa2Acc tile 14 + qt = a[224:255]
-constexpr int FA3_A_Q = 112, FA3_T_O = 10, FA3_T_L = 14;
+// values first; tests/test_host_logic.py verifies after every build that no compiler-generated instruction touches
+// Fa3Map<D>::A_Q and up):
+//   L tile qt = Fa2Acc tile 14 + qt = a[224:255]             O^T tile qt*DT+dt = Fa2Acc tile T_O + qt*DT+dt, right below
+//   ones (A operand, all ones) = the 4 registers below O^T    Q fragment (qt, ks) = a[A_Q + 4 KS qt + 4 ks : +3], below
+template <int D>
+struct Fa3Map {
+  static constexpr int KS = D / 16, DT = D / 32;
+  static constexpr int T_L = 14, T_O = 14 - 2 * DT;
+  static constexpr int A_ONES = 16 * T_O - 4, A_Q = A_ONES - 8 * KS;  // D = 64: 156 / 124, 96: 124 / 76, 128: 92 / 28
+  static constexpr int CPRK = D / 8 + 1;          // 16-byte chunks per padded K row
+  static constexpr int KU = CPRK, VU = D / 8;     // 1-KiB DMA units of the K / V tile of a stage
+  static constexpr int NU = KU + VU, UPW = (NU + 3) / 4;  // units per stage, per wave
+};
 
 template <int R>
 struct Fa3AW;  // write one accumulator register (the clobber makes the register part of the kernel's allocation)
@@ -40,6 +49,90 @@ struct Fa3AW;  // write one accumulator register (the clobber makes the register
       asm volatile("v_accvgpr_write_b32 a" #R ", %0" : : "v"(v) : "a" #R);             \
     }                                                                                  \
   };
+FA3_AW(28)
+FA3_AW(29)
+FA3_AW(30)
+FA3_AW(31)
+FA3_AW(32)
+FA3_AW(33)
+FA3_AW(34)
+FA3_AW(35)
+FA3_AW(36)
+FA3_AW(37)
+FA3_AW(38)
+FA3_AW(39)
+FA3_AW(40)
+FA3_AW(41)
+FA3_AW(42)
+FA3_AW(43)
+FA3_AW(44)
+FA3_AW(45)
+FA3_AW(46)
+FA3_AW(47)
+FA3_AW(48)
+FA3_AW(49)
+FA3_AW(50)
+FA3_AW(51)
+FA3_AW(52)
+FA3_AW(53)
+FA3_AW(54)
+FA3_AW(55)
+FA3_AW(56)
+FA3_AW(57)
+FA3_AW(58)
+FA3_AW(59)
+FA3_AW(60)
+FA3_AW(61)
+FA3_AW(62)
+FA3_AW(63)
+FA3_AW(64)
+FA3_AW(65)
+FA3_AW(66)
+FA3_AW(67)
+FA3_AW(68)
+FA3_AW(69)
+FA3_AW(70)
+FA3_AW(71)
+FA3_AW(72)
+FA3_AW(73)
+FA3_AW(74)
+FA3_AW(75)
+FA3_AW(76)
+FA3_AW(77)
+FA3_AW(78)
+FA3_AW(79)
+FA3_AW(80)
+FA3_AW(81)
+FA3_AW(82)
+FA3_AW(83)
+FA3_AW(84)
+FA3_AW(85)
+FA3_AW(86)
+FA3_AW(87)
+FA3_AW(88)
+FA3_AW(89)
+FA3_AW(90)
+FA3_AW(91)
+FA3_AW(92)
+FA3_AW(93)
+FA3_AW(94)
+FA3_AW(95)
+FA3_AW(96)
+FA3_AW(97)
+FA3_AW(98)
+FA3_AW(99)
+FA3_AW(100)
+FA3_AW(101)
+FA3_AW(102)
+FA3_AW(103)
+FA3_AW(104)
+FA3_AW(105)
+FA3_AW(106)
+FA3_AW(107)
+FA3_AW(108)
+FA3_AW(109)
+FA3_AW(110)
+FA3_AW(111)
 FA3_AW(112)
 FA3_AW(113)
 FA3_AW(114)
@@ -104,17 +197,19 @@ struct Fa3Ops;
       else                                                                                                            \
         asm volatile("v_mfma_f32_32x32x16_" SUF " %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(kf), "n"(R), "n"(R + 3));   \
     }                                                                                                                 \
+    template <int RO>                                                                                                 \
     static __device__ __forceinline__ void lsum0(const X8& pf) {                                                      \
-      asm volatile("v_mfma_f32_32x32x16_" SUF " a[224:239], a[156:159], %0, a[224:239]"                               \
+      asm volatile("v_mfma_f32_32x32x16_" SUF " a[224:239], a[%1:%2], %0, a[224:239]"                                 \
                    :                                                                                                  \
-                   : "v"(pf)                                                                                          \
+                   : "v"(pf), "n"(RO), "n"(RO + 3)                                                                    \
                    : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235",  \
                      "a236", "a237", "a238", "a239");                                                                 \
     }                                                                                                                 \
+    template <int RO>                                                                                                 \
     static __device__ __forceinline__ void lsum1(const X8& pf) {                                                      \
-      asm volatile("v_mfma_f32_32x32x16_" SUF " a[240:255], a[156:159], %0, a[240:255]"                               \
+      asm volatile("v_mfma_f32_32x32x16_" SUF " a[240:255], a[%1:%2], %0, a[240:255]"                                 \
                    :                                                                                                  \
-                   : "v"(pf)                                                                                          \
+                   : "v"(pf), "n"(RO), "n"(RO + 3)                                                                    \
                    : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251",  \
                      "a252", "a253", "a254", "a255");                                                                 \
     }                                                                                                                 \
@@ -123,12 +218,14 @@ FA3_OPS(__bf16, "bf16")
 FA3_OPS(_Float16, "f16")
 #undef FA3_OPS
 
-template <typename T, bool CAUSAL, bool STAMP = false>
+template <typename T, int D, bool CAUSAL, bool STAMP = false>
 __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
   using X8 = typename DT<T>::x8;
   using X4 = typename DT<T>::x4;
   using OPS = Fa3Ops<T>;
-  constexpr int D = 64, QT = 2, KS = 4, DT_ = 2, CPR = 8, NLD = 2;
+  using MAP = Fa3Map<D>;
+  constexpr int QT = 2, KS = MAP::KS, DT_ = MAP::DT, UPW = MAP::UPW;
+  constexpr int FA3_T_O = MAP::T_O, FA3_T_L = MAP::T_L, FA3_A_Q = MAP::A_Q, FA3_A_ONES = MAP::A_ONES;
   using SM = FaSmem<D>;
 #define IC(N) std::integral_constant<int, (N)> {}
 
@@ -157,7 +254,7 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
   // constant MFMA operand: ones = A operand of all ones (row sums)
   {
     const uint32_t o2 = pack2<T>(1.f, 1.f);
-    Fa3AW<156>::w(o2); Fa3AW<157>::w(o2); Fa3AW<158>::w(o2); Fa3AW<159>::w(o2);
+    Fa3AW<FA3_A_ONES + 0>::w(o2); Fa3AW<FA3_A_ONES + 1>::w(o2); Fa3AW<FA3_A_ONES + 2>::w(o2); Fa3AW<FA3_A_ONES + 3>::w(o2);
   }
   const float c2 = p.scale_log2e;
 
@@ -188,7 +285,7 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       const int d0 = 16 * ks + 8 * h;
       u32x4_t raw = *(const u32x4_t*)(qp + (d0 < p.D ? d0 : 0));
       if (!(q_ok[qt] && d0 < p.D)) raw = (u32x4_t){0, 0, 0, 0};
-      constexpr int R = FA3_A_Q + 16 * qt + 4 * ks;
+      constexpr int R = FA3_A_Q + 4 * KS * qt + 4 * ks;
       Fa3AW<R + 0>::w(raw[0]); Fa3AW<R + 1>::w(raw[1]); Fa3AW<R + 2>::w(raw[2]); Fa3AW<R + 3>::w(raw[3]);
     });
 
@@ -283,19 +380,19 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
     const T* kbase = (const T*)p.k + b * p.ks_b + kvh * p.ks_h;
     const T* vbase = (const T*)p.v + b * p.vs_b + kvh * p.vs_h;
     const int d_chunks = p.D >> 3;
-    int st_row[5], st_cb[5];  // per unit slot: key row inside the tile, byte offset of the 16-B chunk in the row
+    int st_row[UPW], st_cb[UPW];  // per unit slot: key row inside the tile, byte offset of the 16-B chunk in the row
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int u = (wave + 4 * i < 17) ? wave + 4 * i : wave;  // 5 units per wave (waves 1..3 repeat their first)
+    for (int i = 0; i < UPW; ++i) {
+      const int u = (wave + 4 * i < MAP::NU) ? wave + 4 * i : wave;  // UPW units per wave (spare slots repeat the first)
       int row, c;
-      if (u < 9) {
+      if (u < MAP::KU) {
         const int u16 = 64 * u + lane;
-        row = u16 / 9;
-        c = u16 % 9;
+        row = u16 / MAP::CPRK;
+        c = u16 % MAP::CPRK;
       } else {
-        const int blk = 2 * (u - 9) + (lane >> 5);
-        row = 8 * (blk >> 1) + ((lane & 31) >> 2);
-        c = 4 * (blk & 1) + (lane & 3);
+        const int blk = 2 * (u - MAP::KU) + (lane >> 5);
+        row = 8 * (blk / DT_) + ((lane & 31) >> 2);
+        c = 4 * (blk % DT_) + (lane & 3);
       }
       c = c < d_chunks ? c : d_chunks - 1;
       st_row[i] = row;
@@ -317,8 +414,8 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
     auto dma_unit = [&](auto I_, int tile_) {
       constexpr int i = decltype(I_)::value;
       const int stage = tile_ & (FA3_STAGES - 1);
-      const int u = (wave + 4 * i < 17) ? wave + 4 * i : wave;  // wave-uniform
-      const bool isk = u < 9;
+      const int u = (wave + 4 * i < MAP::NU) ? wave + 4 * i : wave;  // wave-uniform
+      const bool isk = u < MAP::KU;
       const char* base = isk ? dma_kb : dma_vb;
       const int row = st_row[i] < dma_last ? st_row[i] : dma_last;  // rows past Sk: clamped (branch-free)
       const int off = (int)__umul24((unsigned)row, (unsigned)(isk ? ks2 : vs2)) + st_cb[i];
@@ -332,14 +429,14 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
     };
     auto stage_dma = [&](int tile) {
       dma_tile_base(tile);
-      dma_unit(IC(0), tile); dma_unit(IC(1), tile); dma_unit(IC(2), tile); dma_unit(IC(3), tile); dma_unit(IC(4), tile);
+      fa2_for<UPW>([&](auto I_) { dma_unit(I_, tile); });
     };
 
     __syncthreads();  // the previous pass is done with every LDS stage
     stage_dma(0);
     stage_dma(1);
     stage_dma(2);
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // tiles 0 and 1 have landed, tile 2 may still fly
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW) : "memory");  // tiles 0 and 1 have landed, tile 2 may still fly
     __syncthreads();
 
     f32x16_t S[2][QT][2];   // score tiles: buffer (t & 1), query sub-tile, 32-key half
@@ -375,17 +472,18 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       };
       read_k(IC(0));
       read_k(IC(1));
+      constexpr int NS1 = 4 * KS;  // one QK^T MFMA per step; the 16 exp half-units are spread evenly over the steps
       auto step = [&](auto J_) {
         constexpr int j = decltype(J_)::value;
-        if constexpr (j < 16) {
+        {
           constexpr int ks = j >> 2, qt = (j & 3) >> 1, tt = j & 1;
-          OPS::template qk<FA3_A_Q + 16 * qt + 4 * ks, ks == 0>(S[nb][qt][tt], kf[ks & 1][tt]);
-          if constexpr (j == 3) read_k(IC(2));
-          if constexpr (j == 7) read_k(IC(3));
+          OPS::template qk<FA3_A_Q + 4 * KS * qt + 4 * ks, ks == 0>(S[nb][qt][tt], kf[ks & 1][tt]);
+          if constexpr ((j & 3) == 3 && ks + 2 < KS) read_k(IC(ks + 2));  // the ring slot of k-step ks is free again
         }
         if constexpr (DO_EXP) {
-          if constexpr (j < 16) {
-            constexpr int u = j >> 1, half = j & 1, qt = u >> 2, s = u & 3;
+          constexpr int hu = (j * 16) / NS1, hu_prev = j == 0 ? -1 : ((j - 1) * 16) / NS1;
+          if constexpr (hu != hu_prev) {
+            constexpr int u = hu >> 1, half = hu & 1, qt = u >> 2, s = u & 3;
             constexpr int base = 8 * (s & 1) + 4 * half;
             const float e0 = fast_exp2(S[cb][qt][s >> 1][base + 0]);
             const float e1 = fast_exp2(S[cb][qt][s >> 1][base + 1]);
@@ -396,11 +494,11 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
             pfw[qt][s][2 * half + 0] = w0;
             pfw[qt][s][2 * half + 1] = w1;
           }
-          if constexpr (j == 15) read_v(vb, IC(0));
+          if constexpr (j == NS1 - 1) read_v(vb, IC(0));
         }
         __builtin_amdgcn_sched_barrier(0);
       };
-      fa2_for<16>(step);
+      fa2_for<NS1>(step);
     };
 
     // ---- masks of an edge tile (causal diagonal, keys past Sk) on S[nb]; first key kv0n.  Rare: not overlapped.
@@ -430,20 +528,22 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
     auto phase2 = [&](auto NB_, auto DO_PV_, const char* vb, int dma_tile) {
       constexpr int nb = decltype(NB_)::value;
       constexpr bool DO_PV = decltype(DO_PV_)::value != 0;
+      constexpr int PS = 2 * DT_ + 2, NS2 = 4 * PS;  // per 16-key k-step: 2 DT PV MFMAs + 2 row-sum MFMAs
+      constexpr int DSTEP = (NS2 - 4) / UPW;          // one DMA unit every DSTEP steps
       auto step = [&](auto J_) {
-        constexpr int j = decltype(J_)::value;  // 24 steps: k-step s = j / 6, MFMA m = j % 6
-        constexpr int s = j / 6, m = j % 6;
+        constexpr int j = decltype(J_)::value;
+        constexpr int s = j / PS, m = j % PS;
         if constexpr (DO_PV) {
-          if constexpr (m < 4) {
+          if constexpr (m < 2 * DT_) {
             constexpr int dt = m >> 1, qt = m & 1;
             Fa2Acc<T, FA3_T_O + qt * DT_ + dt>::mfma(vfr[s & 1][dt], __builtin_bit_cast(X8, pfw[qt][s]));
-          } else if constexpr (m == 4) {
-            OPS::lsum0(__builtin_bit_cast(X8, pfw[0][s]));
+          } else if constexpr (m == 2 * DT_) {
+            OPS::template lsum0<FA3_A_ONES>(__builtin_bit_cast(X8, pfw[0][s]));
           } else {
-            OPS::lsum1(__builtin_bit_cast(X8, pfw[1][s]));
+            OPS::template lsum1<FA3_A_ONES>(__builtin_bit_cast(X8, pfw[1][s]));
           }
           if constexpr (m == 1 && s + 1 < 4) read_v(vb, IC(s + 1));  // slot (s+1)&1 was last read by k-step s-1
-          if constexpr (j % 5 == 3 && j / 5 < 5) dma_unit(IC(j / 5), dma_tile);  // steps 3, 8, 13, 18, 23: tile t + 3
+          if constexpr (j >= 3 && (j - 3) % DSTEP == 0 && (j - 3) / DSTEP < UPW) dma_unit(IC((j - 3) / DSTEP), dma_tile);
         }
         // scale-and-subtract + max of 4 scores per step (steps 2..17), in the order the QK^T MFMAs of phase 1 finished
         // writing them: sub-tile qt = i / 8, 32-key half tt = (i / 4) & 1, registers 4 (i & 3) .. +3
@@ -470,7 +570,7 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       };
-      fa2_for<24>(step);
+      fa2_for<NS2>(step);
     };
 
     // ---- reference update for the tile in S[nb] (rare after the first tiles: deferred-rescale threshold).  One
@@ -511,8 +611,7 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
             Fa2AccIO<k>::template write4<2>(v[2]);
             Fa2AccIO<k>::template write4<3>(v[3]);
           };
-          rescale(IC(FA3_T_O + qt * DT_ + 0));
-          rescale(IC(FA3_T_O + qt * DT_ + 1));
+          fa2_for<DT_>([&](auto DTI) { rescale(IC(FA3_T_O + qt * DT_ + decltype(DTI)::value)); });
           rescale(IC(FA3_T_L + qt));
           negref[qt] = -ref_new;
         });
@@ -532,7 +631,7 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
     // ---- tiles this wave computes (two per trip: the score buffers alternate), then the tiles it only helps to
     // move (other waves of the workgroup still need them: causal, this wave's rows end earlier)
     auto land = [&]() {  // end of an iteration: this wave's share of tile t + 2 has landed (tile t + 3 may still fly)
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW) : "memory");
       __syncthreads();
     };
     unsigned long long st_sum[5] = {0, 0, 0, 0, 0};  // diagnostic build: cycles in phase 1 / mask / phase 2 / update / land

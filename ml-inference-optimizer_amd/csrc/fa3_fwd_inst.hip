@@ -2,9 +2,7 @@
 #include <cstdlib>
 
 #include "fa3_fwd2_kernel.h"
-#if FA_D == 64
 #include "fa3_fwd3_kernel.h"
-#endif
 
 #if FA_TYPE_ID == 0
 using FaT = __bf16;
@@ -51,17 +49,16 @@ static int launch_two(FaDev p, hipStream_t stream) {
   return 0;
 }
 
-#if FA_D == 64
-// third structure (software-pipelined across KV tiles): head dim 64, no user mask
+// third structure (software-pipelined across KV tiles): no user mask
 template <bool CAUSAL>
 static int launch_three(FaDev p, hipStream_t stream) {
   p.nqblk = (p.Sq + FA3_BM - 1) / FA3_BM;
   p.qgrid = CAUSAL ? (p.nqblk + 1) / 2 : p.nqblk;
   const int grid = p.qgrid * p.B * p.H;
-  const size_t smem = FA3_STAGES * FaSmem<64>::STAGE;
-  auto kern = fa3_fwd3_kernel<FaT, CAUSAL>;
+  const size_t smem = FA3_STAGES * FaSmem<FA_D>::STAGE;
+  auto kern = fa3_fwd3_kernel<FaT, FA_D, CAUSAL>;
   if (const char* e = std::getenv("MIO_FA_DBG_PTR")) {  // diagnostic build with in-kernel phase stamps (tools/fa_stamps.py)
-    kern = fa3_fwd3_kernel<FaT, CAUSAL, true>;
+    kern = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, true>;
     p.mask = (const void*)std::strtoull(e, nullptr, 0);
   }
   static bool attr_set = false;
@@ -75,7 +72,6 @@ static int launch_three(FaDev p, hipStream_t stream) {
   if (e != hipSuccess) return mio_fail(std::string("fa3_fwd3 launch: ") + hipGetErrorString(e));
   return 0;
 }
-#endif
 
 static int fa_impl() {  // MIO_FA_IMPL=1 / 2 / 3 force one structure for A/B runs (0 = the rule in fa3_launch)
   static const int v = [] {
@@ -87,17 +83,14 @@ static int fa_impl() {  // MIO_FA_IMPL=1 / 2 / 3 force one structure for A/B run
 
 template <>
 int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t stream) {
-  // Structure choice (measured on MI355X, B8 S4096 H16, random data; MIO_FA_IMPL=1 / 2 / 3 forces one for A/B runs):
-  //   head dim 64, no user mask: the software-pipelined kernel (causal 0.359 ms vs 0.442 for the two-waves-per-SIMD
-  //     kernel and 0.52 for the sequential one-wave kernel; non-causal 0.626 vs 0.79);
-  //   head dim 96 / 128, no user mask: the one-wave-per-SIMD / 64-rows-per-wave kernel (D128 causal 760 vs 555 TFLOP/s,
-  //     D80 595 vs 407);
+  // Structure choice (measured on MI355X, B8 S4096, random data; MIO_FA_IMPL=1 / 2 / 3 forces one for A/B runs):
+  //   no user mask, Sq > 128: the software-pipelined kernel at every head dim --
+  //     D64 causal 0.359 ms (766 TFLOP/s) vs 0.442 two-waves-per-SIMD / 0.52 sequential one-wave; non-causal 0.626 vs 0.79;
+  //     D128 causal 0.284 ms (967 TFLOP/s) vs 0.361 sequential one-wave; D80 non-causal 0.828 ms (830) vs 1.158;
   //   user masks and Sq <= 128: the two-waves-per-SIMD kernel.
-#if FA_D == 64
   if ((fa_impl() == 3 || fa_impl() == 0) && mask_kind == MIO_MASK_NONE && p.Sq > 128)
     return causal ? launch_three<true>(p, stream) : launch_three<false>(p, stream);
-#endif
-  const bool two = (fa_impl() == 2) || (fa_impl() != 1 && (FA_D > 64 || !causal));
+  const bool two = (fa_impl() == 2);
   if (mask_kind == MIO_MASK_NONE && two && p.Sq > 128)
     return causal ? launch_two<true>(p, stream) : launch_two<false>(p, stream);
   if (causal) {

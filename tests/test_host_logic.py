@@ -264,29 +264,30 @@ def test_ring_attention_config_and_shells():
         cross(torch.zeros(1, 4, 32), torch.zeros(1, 4, 32))
 
 
-@pytest.mark.parametrize("type_id", [0, 1])
-def test_fwd3_accumulator_registers_untouched_by_compiler(tmp_path, type_id):
-    """fa3_fwd3_kernel keeps O^T, L, Q and the ones operand in accumulator registers a112..a255 that only its inline
-    asm names.  The allocator does not know they are live between asm statements, so the build is only sound if no
-    compiler-generated instruction touches them: check the ISA of every instantiation (tools/check_agpr.py)."""
+@pytest.mark.parametrize("type_id,D", [(0, 64), (1, 64), (0, 96), (0, 128)])
+def test_fwd3_accumulator_registers_untouched_by_compiler(tmp_path, type_id, D):
+    """fa3_fwd3_kernel keeps O^T, L, Q and the ones operand in accumulator registers Fa3Map<D>::A_Q .. a255 that only
+    its inline asm names.  The allocator does not know they are live between asm statements, so the build is only sound
+    if no compiler-generated instruction touches them: check the ISA of every instantiation (tools/check_agpr.py)."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     csrc = os.path.join(ROOT, "ml-inference-optimizer_amd", "csrc")
-    isa = tmp_path / "fa64.s"
+    isa = tmp_path / "fa.s"
     subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I../../include", "-I.", "-Wno-unused-value",
-                    "-mllvm", "-amdgpu-mfma-vgpr-form", f"-DFA_TYPE_ID={type_id}", "-DFA_D=64", "-S", "--cuda-device-only",
-                    "fa3_fwd_inst.hip", "-o", str(isa)], cwd=csrc, check=True, capture_output=True)
+                    "-mllvm", "-amdgpu-mfma-vgpr-form", f"-DFA_TYPE_ID={type_id}", f"-DFA_D={D}", "-S",
+                    "--cuda-device-only", "fa3_fwd_inst.hip", "-o", str(isa)], cwd=csrc, check=True, capture_output=True)
     text = isa.read_text().splitlines()
     starts = [i for i, l in enumerate(text) if re.match(r"^_Z15fa3_fwd3_kernel\w+:", l)]
     assert len(starts) >= 2, "causal and full instantiations expected"
+    floor = 16 * (14 - 2 * (D // 32)) - 4 - 8 * (D // 16)  # Fa3Map<D>::A_Q
     for a in starts:
         b = next(i for i in range(a, len(text)) if "s_endpgm" in text[i])
         part = tmp_path / "k.s"
         part.write_text("\n".join(text[a:b + 1]))
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_agpr.py"), str(part), "112"],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_agpr.py"), str(part), str(floor)],
                            capture_output=True, text=True)
         assert r.returncode == 0, text[a] + "\n" + r.stdout
         assert not any("scratch_" in l for l in text[a:b + 1]), "register spills in " + text[a]
