@@ -61,9 +61,11 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
   __amdgpu_buffer_rsrc_t yrs_prev = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0, 0x00020000);
   // after the exchange a lane holds row (2*mtp + (g&1))*16 + c16 of the wave tile, columns 8*(g>>1) .. +7 of
   // 16-column tile nt: byte offset of chunk (mtp, nt) = yoff0 + mtp * 64*ldy + nt * 32
+  // (GemmDev::y_blk: the tile's 8 K-tile blocks of the consumer are 16 KiB apart, a row is 64 B inside a block)
   const int yrow0 = wr * 128 + (g & 1) * 16 + c16;
-  const int yoff0 = (yrow0 * (int)p.ldy + wc * 128 + 8 * (g >> 1)) * 2;
-  const int ystep = 64 * (int)p.ldy;
+  const int yoff0 = p.y_blk ? (wc * 4 << 14) + yrow0 * 64 + 16 * (g >> 1)
+                            : (yrow0 * (int)p.ldy + wc * 128 + 8 * (g >> 1)) * 2;
+  const int ystep = p.y_blk ? 32 * 64 : 64 * (int)p.ldy;
   int nchunks_prev = 0;    // 32 once a tile is pending (wave-uniform)
   bool full_prev = false;  // previous tile lies completely inside M x N: no per-lane masks (wave-uniform)
   int mrem_prev = 0;       // rows of the previous tile inside M
@@ -92,20 +94,28 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
       const int kch = pcs ^ g6_swz(row);
       const int xr = (row < mrem) ? row : (int)(mrem - 1);
       const int wrw = (row < nrem) ? row : (nrem - 1);
-      xvo[i] = xr * (int)p.ldx * 2 + 16 * kch;
+      xvo[i] = (p.x_blk ? xr * 64 : xr * (int)p.ldx * 2) + 16 * kch;
       wvo[i] = wrw * (int)p.ldw * 2 + 16 * kch;
     }
-    xrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.x + m0 * p.ldx), 0, 0x7fffffff, 0x00020000);
+    xrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.x_blk ? (void*)((const char*)p.x + ((int64_t)tm * nk << 14)) : (void*)((const T*)p.x + m0 * p.ldx), 0, 0x7fffffff,
+        0x00020000);
     wrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.w + (int64_t)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
   };
 
 #define IC(N) std::integral_constant<int, N>{}
+  const int krot = ((int)(blockIdx.x & 7) * nk) >> 3;  // XCD = blockIdx.x % 8
+  const int xkstep = p.x_blk ? 16384 : G6_BK * 2;      // bytes from one K-tile of x to the next (GemmDev::x_blk)
   int sbase = 0;  // LDS stage of the current tile's K-tile 0 (the stage index runs on across tiles)
   // request piece (i, which) of K-tile `kl` of the tile `setup` describes into stage (sbase + ks) & 3
   auto issue_one = [&](int ks, int kl, auto I, auto WHICH) {
     constexpr int i = decltype(I)::value, which = decltype(WHICH)::value;
     char* dst = smem + ((sbase + ks) & (G6_STAGES - 1)) * G6_BUF + which * G6_XT + (wave * 4 + i) * 1024;
-    const int koff = kl * (G6_BK * 2);
+    // K-tiles are visited in a rotated order, a different rotation per XCD (the sum over k does not care): with a
+    // row stride of 8 KiB (K = 4096) every workgroup on the chip otherwise asks the same few memory channels for the
+    // same k at the same time
+    const int kr = kl + krot;
+    const int koff = (kr >= nk ? kr - nk : kr) * (which ? G6_BK * 2 : xkstep);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? wrs : xrs, (MIO_LDS void*)dst, 16, which ? wvo[i] : xvo[i],
                                              koff, 0, 0);
   };
@@ -161,7 +171,8 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
         st_off = off;
       }
       if constexpr (ph == 1 || ph == 3) st_d = (u32x4_t){ob0[chunk], ob1[chunk], ob2[chunk], ob3[chunk]};
-      if constexpr (ph == 2 || ph == 3) __builtin_amdgcn_raw_buffer_store_b128(st_d, yrs_prev, st_off, nt * 32, 0);
+      if constexpr (ph == 2 || ph == 3)
+        __builtin_amdgcn_raw_buffer_store_b128(st_d, yrs_prev, st_off, p.y_blk ? ((nt >> 1) << 14) + ((nt & 1) << 5) : nt * 32, 0);
     }
   };
   // One K-tile (see gemm4w16_kernel) + SPK stores of the previous tile (SPK = 1: phases in micro-steps 12, 13, 14;
@@ -294,7 +305,10 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
       }
     }
     // where this tile's chunks go
-    yrs_prev = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.y + om0 * p.ldy + on0), 0, 0x7fffffff, 0x00020000);
+    yrs_prev = __builtin_amdgcn_make_buffer_rsrc(
+        p.y_blk ? (void*)((char*)p.y + (((om0 >> 8) * (int64_t)(p.N >> 5) + (on0 >> 5)) << 14))
+                : (void*)((T*)p.y + om0 * p.ldy + on0),
+        0, 0x7fffffff, 0x00020000);
     nchunks_prev = 32;
     full_prev = (omrem == 256) && (onrem >= 256);
     mrem_prev = omrem;
@@ -315,7 +329,7 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
       const bool ok = (nt < nvalid_prev) && (yrow0 + 32 * mtp < mrem_prev);
       const int off = ok ? yoff0 + mtp * ystep : 0x7fffffff;
       const u32x4_t d = {ob0[j], ob1[j], ob2[j], ob3[j]};
-      __builtin_amdgcn_raw_buffer_store_b128(d, yrs_prev, off, nt * 32, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(d, yrs_prev, off, p.y_blk ? ((nt >> 1) << 14) + ((nt & 1) << 5) : nt * 32, 0);
       if constexpr (j + 1 < 32) self(self, IC(j + 1));
     };
     flush(flush, IC(0));

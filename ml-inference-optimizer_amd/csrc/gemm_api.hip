@@ -1,8 +1,28 @@
 // C-ABI entry points mio_gemm_bias_act / mio_fused_mlp_fwd (see include/mio_hip.h).
+#include <cstdlib>
+#include <string>
+
 #include "gemm_kernel.h"
 
 extern template int gemm_launch<__bf16>(GemmDev, int, hipStream_t);
 extern template int gemm_launch<_Float16>(GemmDev, int, hipStream_t);
+
+// MIO_GEMM_IMPL=v1|8p|4w|2x|4wp|4w16 selects an older pipeline for A/B comparisons (read once); 0 = default dispatch.
+int mio_gemm_impl() {
+  static const int v = [] {
+    const char* e = std::getenv("MIO_GEMM_IMPL");
+    if (e == nullptr) return 0;
+    const std::string s(e);
+    if (s == "v1") return 1;
+    if (s == "8p") return 2;
+    if (s == "4w") return 3;
+    if (s == "2x") return 4;
+    if (s == "4wp") return 5;
+    if (s == "4w16") return 6;
+    return 0;
+  }();
+  return v;
+}
 
 static int gemm_dispatch(const GemmDev& p, int act, int dtype, hipStream_t st) {
   if (dtype == MIO_BF16) return gemm_launch<__bf16>(p, act, st);
@@ -30,13 +50,26 @@ extern "C" int mio_gemm_bias_act(const void* x, const void* w, const void* bias,
   p.x = x; p.w = w; p.wg = w_gate; p.bias = bias; p.bias_g = bias_gate; p.res = residual; p.y = y;
   p.M = M; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldr = ldr; p.N = N; p.K = K;
   p.tiles_m = p.tiles_n = 0;
+  p.x_blk = p.y_blk = 0;
   p.dbg = nullptr;
   return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
 }
 
+// Both GEMMs of the MLP take a 256x256-tile 16x16x32 kernel (gemm_inst.hip launch_act) and stage 1 the persistent one:
+// then the intermediate can use the blocked layout (GemmDev::x_blk / y_blk).
+static bool mlp_blocked_ok(int64_t M, int32_t d, int32_t I, int32_t act, bool residual) {
+  (void)residual;
+  if (act == MIO_ACT_SWIGLU || (mio_gemm_impl() != 0 && mio_gemm_impl() != 5)) return false;
+  const int64_t tm = (M + 255) / 256;
+  const bool big1 = tm * ((I + 255) / 256) >= 256, big2 = tm * ((d + 255) / 256) >= 256;
+  const bool fits = (int64_t)d * 512 < 0x7fffffff && (int64_t)I * 512 < 0x7fffffff;
+  return big1 && big2 && fits && d % 64 == 0 && d >= 256 && I % 256 == 0 && d % 8 == 0;
+}
+
 extern "C" size_t mio_fused_mlp_workspace_bytes(int64_t M, int32_t d, int32_t I, int32_t act) {
   (void)d; (void)act;
-  return (size_t)M * (size_t)I * 2;
+  const int64_t mp = (M + 255) / 256 * 256;  // whole 256-row blocks (blocked intermediate layout)
+  return (size_t)mp * (size_t)I * 2;
 }
 
 extern "C" int mio_fused_mlp_fwd(const void* x, const void* w1, const void* b1, const void* wg, const void* bg,
@@ -44,6 +77,26 @@ extern "C" int mio_fused_mlp_fwd(const void* x, const void* w1, const void* b1, 
                                  int64_t M, int32_t d, int32_t I, int32_t act, int32_t dtype, void* stream) {
   MIO_CHECK(workspace != nullptr || M == 0, "mio_fused_mlp_fwd: workspace must be non-null");
   MIO_CHECK(act != MIO_ACT_NONE, "mio_fused_mlp_fwd: an activation is required");
+  if (M > 0 && mlp_blocked_ok(M, d, I, act, residual != nullptr)) {
+    MIO_CHECK(x && w1 && w2 && y, "mio_fused_mlp_fwd: x, w1, w2, y must be non-null");
+    MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_fused_mlp_fwd: dtype must be bf16 or fp16");
+    MIO_CHECK(mio_aligned16(x) && mio_aligned16(w1) && mio_aligned16(w2) && mio_aligned16(y) && mio_aligned16(b1) &&
+                  mio_aligned16(b2) && mio_aligned16(residual) && mio_aligned16(workspace),
+              "mio_fused_mlp_fwd: pointers must be 16-byte aligned");
+    GemmDev p;
+    p.x = x; p.w = w1; p.wg = nullptr; p.bias = b1; p.bias_g = nullptr; p.res = nullptr; p.y = workspace;
+    p.M = M; p.ldx = d; p.ldw = d; p.ldy = I; p.ldr = 0; p.N = I; p.K = d;
+    p.tiles_m = p.tiles_n = 0;
+    p.x_blk = 0; p.y_blk = 1;
+    p.dbg = nullptr;
+    int rc = gemm_dispatch(p, act, dtype, (hipStream_t)stream);
+    if (rc != 0) return rc;
+    p.x = workspace; p.w = w2; p.bias = b2; p.res = residual; p.y = y;
+    p.ldx = I; p.ldw = I; p.ldy = d; p.ldr = d; p.N = d; p.K = I;
+    p.tiles_m = p.tiles_n = 0;
+    p.x_blk = 1; p.y_blk = 0;
+    return gemm_dispatch(p, MIO_ACT_NONE, dtype, (hipStream_t)stream);
+  }
   // stage 1: h = act(x w1^T + b1) [* silu-gate], written once in the storage dtype
   int rc = mio_gemm_bias_act(x, w1, b1, wg, bg, nullptr, workspace, M, I, d, d, d, I, 0, act, dtype, stream);
   if (rc != 0) return rc;

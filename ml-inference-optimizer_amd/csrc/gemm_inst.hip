@@ -176,21 +176,7 @@ static int launch_2x(GemmDev p, hipStream_t stream) {
   return 0;
 }
 
-// MIO_GEMM_IMPL=v1|8p selects an older pipeline for A/B comparisons (read once); default = 4-wave kernel.
-static int gemm_impl() {
-  static const int v = [] {
-    const char* e = std::getenv("MIO_GEMM_IMPL");
-    if (e == nullptr) return 0;
-    if (std::string(e) == "v1") return 1;
-    if (std::string(e) == "8p") return 2;
-    if (std::string(e) == "4w") return 3;
-    if (std::string(e) == "2x") return 4;
-    if (std::string(e) == "4wp") return 5;
-    if (std::string(e) == "4w16") return 6;
-    return 0;
-  }();
-  return v;
-}
+static int gemm_impl() { return mio_gemm_impl(); }  // MIO_GEMM_IMPL (gemm_api.hip)
 
 template <int ACT>
 static int launch_act(const GemmDev& p, hipStream_t stream) {

@@ -29,8 +29,15 @@ struct GemmDev {
   int64_t M, ldx, ldw, ldy, ldr;
   int N, K;
   int tiles_m, tiles_n;
+  // Blocked activation layout (FusedMLP's intermediate only, set by mio_fused_mlp_fwd): element (m, k) lives at byte
+  // ((m / 256 * (K / 32) + k / 32) * 256 + m % 256) * 64 + (k % 32) * 2, i.e. every (256-row, 32-column) K-tile of
+  // the consuming GEMM is one contiguous 16 KiB block.  With the plain [M, I] layout a K-tile is 256 pieces of 64 B
+  // at a stride of 2 I bytes: at I = 4096 that access pattern, not the matrix pipe, bounds the second GEMM.
+  int x_blk, y_blk;
   unsigned long long* dbg;  // diagnostic builds only (in-kernel stamps); nullptr otherwise
 };
+
+int mio_gemm_impl();  // MIO_GEMM_IMPL override (0 = default dispatch); defined in gemm_api.hip
 
 constexpr int GEMM_BK = 64;
 

@@ -319,7 +319,8 @@ def fused_mlp(
         if w_.dtype != hidden_states.dtype or not w_.is_contiguous():
             raise ValueError("weights must be contiguous and of the input dtype")
     out = torch.empty_like(hidden_states, memory_format=torch.contiguous_format)
-    work = torch.empty(M, I, dtype=hidden_states.dtype, device=hidden_states.device)
+    # workspace in whole 256-row blocks (mio_fused_mlp_workspace_bytes): the intermediate may use a blocked layout
+    work = torch.empty((M + 255) // 256 * 256, I, dtype=hidden_states.dtype, device=hidden_states.device)
     r2 = None
     if residual is not None:
         r2 = residual.reshape(-1, d)

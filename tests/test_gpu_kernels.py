@@ -274,6 +274,34 @@ def test_gemm_edges_and_residual(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("act,res,M", [("gelu", True, 16384 + 100), ("relu", False, 16384), ("silu", True, 20000)])
+def test_fused_mlp_blocked_intermediate(dtype, act, res, M):
+    """FusedMLP at a size where both GEMMs run the 256x256-tile kernels: the [M, I] intermediate then lives in the
+    blocked layout (one contiguous 16 KiB block per 256 rows x 32 columns) between the persistent stage-1 kernel's
+    trickled stores and the stage-2 kernel's DMA loads; ragged M exercises the partly filled last row block.
+    Checker: fp32 CPU matmuls on the same 16-bit inputs + the oracle's activation (too large for the fp64 oracle)."""
+    ops = _ops()
+    from oracle.mlp import gelu_tanh
+    torch.manual_seed(9)
+    d, I = 1024, 1024
+    x = torch.randn(1, M, d).to(dtype)
+    w1 = (torch.randn(I, d) * 0.03).to(dtype)
+    b1 = (torch.randn(I) * 0.1).to(dtype)
+    w2 = (torch.randn(d, I) * 0.03).to(dtype)
+    b2 = (torch.randn(d) * 0.1).to(dtype)
+    r = torch.randn(1, M, d).to(dtype) if res else None
+    y = ops.fused_mlp(x.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), act,
+                      residual=None if r is None else r.to(DEV))
+    h = x[0].float() @ w1.float().T + b1.float()
+    h = {"gelu": gelu_tanh, "relu": torch.relu, "silu": torch.nn.functional.silu}[act](h).to(dtype).float()
+    ref = (h @ w2.float().T + b2.float()).double()
+    if r is not None:
+        ref = ref + r[0].double()
+    rel = ((y[0].float().cpu().double() - ref).abs().mean() / ref.abs().mean()).item()
+    assert rel < (2e-3 if dtype == torch.float16 else 1e-2), f"rel_err={rel:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,act,res", [
     (4096 + 37, 4096 + 8, 1024, "none", False),   # persistent kernel, 1 store / K-tile, ragged M and N, 289 tiles
     (8192, 2304 + 24, 256, "gelu", False),        # persistent, 4 stores / K-tile, 320 tiles
