@@ -73,6 +73,8 @@ def kernel_rooflines(model, x, iters=10):
     w1, b1 = blk.mlp.mlp.fc1.weight, blk.mlp.mlp.fc1.bias
     w2, b2 = blk.mlp.mlp.fc2.weight, blk.mlp.mlp.fc2.bias
     I = w1.shape[0]
+    # weights in the blocked layout, as the modules hand them over at this size (mio/_nn.py linear)
+    wqkv_b, wo_b, w1_b, w2_b = (ops.block_weight(t) for t in (wqkv, wo, w1, w2))
     ln1 = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
     qkv = ops.gemm_bias_act(ln1, wqkv, bqkv)
     q = qkv[:, :, :d].view(B, S, H, D)
@@ -86,13 +88,13 @@ def kernel_rooflines(model, x, iters=10):
     t = _events_ms(lambda: ops.fa3_fwd(q, k, v, causal=True), iters)
     out["fa3_fwd3_kernel<bf16,causal>"] = dict(ms=t, launches=1, flops=2.0 * B * S * (S + 1) * d)
 
-    t = _events_ms(lambda: ops.gemm_bias_act(ln1, wqkv, bqkv, out=o3), iters)
+    t = _events_ms(lambda: ops.gemm_bias_act(ln1, wqkv, bqkv, out=o3, w_blocked=wqkv_b), iters)
     out["gemm4w16p_kernel<bf16,none>"] = dict(ms=t, launches=1, flops=2.0 * M * d * 3 * d)  # qkv
     # the MLP as the model runs it: fc1 + GELU (persistent kernel) writes the blocked intermediate, fc2 + residual reads it
-    t = _events_ms(lambda: ops.fused_mlp(ln2, w1, b1, w2, b2, "gelu", residual=att), iters)
+    t = _events_ms(lambda: ops.fused_mlp(ln2, w1, b1, w2, b2, "gelu", residual=att, fc1_blocked=w1_b, fc2_blocked=w2_b), iters)
     out["fused_mlp: gemm4w16p_kernel<bf16,gelu_tanh> + gemm4w16_kernel<bf16,none>"] = dict(
-        ms=t, launches=2, flops=4.0 * M * d * I)
-    t = _events_ms(lambda: ops.gemm_bias_act(ctx, wo, bo, residual=x, out=o1), iters)
+        ms=t, launches=2, flops=4.0 * M * d * I, combined=True)  # two different kernels: not a roofline candidate
+    t = _events_ms(lambda: ops.gemm_bias_act(ctx, wo, bo, residual=x, out=o1, w_blocked=wo_b), iters)
     out["gemm4w16_kernel<bf16,none> (out-proj)"] = dict(ms=t, launches=1, flops=2.0 * M * d * d)
     t = _events_ms(lambda: ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias), iters)
     out["layernorm_kernel<bf16>"] = dict(ms=2 * t, launches=2, bytes=2 * 2.0 * M * d * 2)
@@ -195,7 +197,8 @@ def main():
     if not a.no_extra and rank == 0 and N == 1:
         try:
             ks = kernel_rooflines(model, x)
-            dom = max((k for k in ks if "flops" in ks[k]), key=lambda k: ks[k]["ms"])
+            dom = max((k for k in ks if "flops" in ks[k] and not ks[k].get("combined")),
+                      key=lambda k: ks[k]["ms"] / ks[k]["launches"])
             kd = ks[dom]
             per_launch_ms = kd["ms"] / kd["launches"]
             ach = kd["flops"] / kd["launches"] / (per_launch_ms * 1e-3) / 1e12

@@ -119,11 +119,31 @@ int mio_gemm_bias_act(const void* x, const void* w, const void* bias, const void
  *           (kernels/triton/mlp_kernels.py:648-756, launch :711) and FusedMLP._forward_triton's
  *           fused_mlp_forward call (kernels/mlp/fused_mlp.py:131-141).
  * x [M,d], w1/wg [I,d], w2 [d,I], biases nullable; workspace >= mio_fused_mlp_workspace_bytes()
- * holds the bf16/fp16 [M,I] activation (written once by stage 1's epilogue, read once by stage 2). */
+ * holds the bf16/fp16 [M,I] activation (written once by stage 1's epilogue, read once by stage 2; rows rounded up
+ * to whole 256-row blocks: at sizes where both GEMMs run the 256x256-tile kernels the library keeps it in a blocked
+ * layout of contiguous 16 KiB K-tiles). */
 size_t mio_fused_mlp_workspace_bytes(int64_t M, int32_t d, int32_t I, int32_t act);
 int mio_fused_mlp_fwd(const void* x, const void* w1, const void* b1, const void* wg, const void* bg,
                       const void* w2, const void* b2, const void* residual, void* y, void* workspace,
                       int64_t M, int32_t d, int32_t I, int32_t act, int32_t dtype, void* stream);
+
+/* Blocked weights: a one-time repack of an nn.Linear weight [N, K] (K % 32 == 0) so that every (256-row, 32-column)
+ * K-tile the 256x256-tile GEMM kernels fetch is one contiguous 16 KiB block instead of 256 pieces of 64 B at a stride of
+ * 2 K bytes:   wb[((n / 256) * (K / 32) + k / 32) * 256 + n % 256][k % 32],  rows padded with zeros to a multiple of 256
+ * (mio_weight_blocked_bytes).  The reference has no counterpart (its weights stay nn.Linear tensors read by tl.load,
+ * kernels/triton/mlp_kernels.py:91-126); the plain-weight entry points above remain the drop-in boundary.
+ * *_ok() == 0: the shape does not take those kernels -- keep the plain weight and call the plain entry point
+ * (the *_bw entry points return an error then). */
+size_t mio_weight_blocked_bytes(int32_t N, int32_t K);
+int mio_weight_block(const void* w, int64_t ldw, void* wb, int32_t N, int32_t K, int32_t dtype, void* stream);
+int32_t mio_gemm_blocked_weight_ok(int64_t M, int32_t N, int32_t K, int32_t act);
+int mio_gemm_bias_act_bw(const void* x, const void* wb, const void* bias, const void* residual, void* y, int64_t M,
+                         int32_t N, int32_t K, int64_t ldx, int64_t ldy, int64_t ldr, int32_t act, int32_t dtype,
+                         void* stream);
+int32_t mio_fused_mlp_blocked_weight_ok(int64_t M, int32_t d, int32_t I, int32_t act);
+int mio_fused_mlp_fwd_bw(const void* x, const void* w1b, const void* b1, const void* w2b, const void* b2,
+                         const void* residual, void* y, void* workspace, int64_t M, int32_t d, int32_t I, int32_t act,
+                         int32_t dtype, void* stream);
 
 /* LayerNorm / residual+LayerNorm rows (the step either side of attention):
  * sum = x + alpha*residual (if residual), y = (sum-mean)/sqrt(var+eps)*weight + bias.

@@ -143,14 +143,16 @@ __global__ __launch_bounds__(256) void gemm4w16_kernel(const GemmDev p) {
     const int xr = (row < mrem) ? row : (int)(mrem - 1);
     const int wrw = (row < nrem) ? row : (nrem - 1);
     xvo[i] = (p.x_blk ? xr * 64 : xr * (int)p.ldx * 2) + 16 * kch;
-    wvo[i] = wrw * (int)p.ldw * 2 + 16 * kch;
+    wvo[i] = (p.w_blk ? wrw * 64 : wrw * (int)p.ldw * 2) + 16 * kch;
   }
-  const int xkstep = p.x_blk ? 16384 : G6_BK * 2;  // bytes from one K-tile of x to the next
+  const int xkstep = p.x_blk ? 16384 : G6_BK * 2;  // bytes from one K-tile of x / w to the next
+  const int wkstep = p.w_blk ? 16384 : G6_BK * 2;
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       p.x_blk ? (void*)((const char*)p.x + ((int64_t)tm * nk << 14)) : (void*)((const T*)p.x + m0 * p.ldx), 0, 0x7fffffff,
       0x00020000);
-  const __amdgpu_buffer_rsrc_t wrs =
-      __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.w + (int64_t)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      p.w_blk ? (void*)((const char*)p.w + ((int64_t)tn * nk << 14)) : (void*)((const T*)p.w + (int64_t)n0 * p.ldw), 0,
+      0x7fffffff, 0x00020000);
 
   // issue ONE 1-KiB piece (piece i of X if which == 0, of W if which == 1) of K-tile kt into stage kt % 4.
   // Branch-free: past the last K-tile the last one is simply re-fetched into an idle stage.
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm4w16_kernel(const GemmDev p) {
     constexpr int i = decltype(I)::value, which = decltype(WHICH)::value;
     const int kte = kt < nk ? kt : nk - 1;
     char* dst = smem + (kt & (G6_STAGES - 1)) * G6_BUF + which * G6_XT + (wave * 4 + i) * 1024;
-    const int koff = kte * (which ? G6_BK * 2 : xkstep);  // bytes
+    const int koff = kte * (which ? wkstep : xkstep);  // bytes
     __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? wrs : xrs, (MIO_LDS void*)dst, 16, which ? wvo[i] : xvo[i], koff,
                                              0, 0);
   };

@@ -95,17 +95,20 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
       const int xr = (row < mrem) ? row : (int)(mrem - 1);
       const int wrw = (row < nrem) ? row : (nrem - 1);
       xvo[i] = (p.x_blk ? xr * 64 : xr * (int)p.ldx * 2) + 16 * kch;
-      wvo[i] = wrw * (int)p.ldw * 2 + 16 * kch;
+      wvo[i] = (p.w_blk ? wrw * 64 : wrw * (int)p.ldw * 2) + 16 * kch;
     }
     xrs = __builtin_amdgcn_make_buffer_rsrc(
         p.x_blk ? (void*)((const char*)p.x + ((int64_t)tm * nk << 14)) : (void*)((const T*)p.x + m0 * p.ldx), 0, 0x7fffffff,
         0x00020000);
-    wrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.w + (int64_t)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+    wrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.w_blk ? (void*)((const char*)p.w + ((int64_t)tn * nk << 14)) : (void*)((const T*)p.w + (int64_t)n0 * p.ldw), 0,
+        0x7fffffff, 0x00020000);
   };
 
 #define IC(N) std::integral_constant<int, N>{}
   const int krot = ((int)(blockIdx.x & 7) * nk) >> 3;  // XCD = blockIdx.x % 8
-  const int xkstep = p.x_blk ? 16384 : G6_BK * 2;      // bytes from one K-tile of x to the next (GemmDev::x_blk)
+  const int xkstep = p.x_blk ? 16384 : G6_BK * 2;  // bytes from one K-tile of x / w to the next (GemmDev::x_blk, w_blk)
+  const int wkstep = p.w_blk ? 16384 : G6_BK * 2;
   int sbase = 0;  // LDS stage of the current tile's K-tile 0 (the stage index runs on across tiles)
   // request piece (i, which) of K-tile `kl` of the tile `setup` describes into stage (sbase + ks) & 3
   auto issue_one = [&](int ks, int kl, auto I, auto WHICH) {
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
     // row stride of 8 KiB (K = 4096) every workgroup on the chip otherwise asks the same few memory channels for the
     // same k at the same time
     const int kr = kl + krot;
-    const int koff = (kr >= nk ? kr - nk : kr) * (which ? G6_BK * 2 : xkstep);
+    const int koff = (kr >= nk ? kr - nk : kr) * (which ? wkstep : xkstep);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? wrs : xrs, (MIO_LDS void*)dst, 16, which ? wvo[i] : xvo[i],
                                              koff, 0, 0);
   };

@@ -51,6 +51,7 @@ extern "C" int mio_gemm_bias_act(const void* x, const void* w, const void* bias,
   p.M = M; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldr = ldr; p.N = N; p.K = K;
   p.tiles_m = p.tiles_n = 0;
   p.x_blk = p.y_blk = 0;
+  p.w_blk = 0;
   p.dbg = nullptr;
   return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
 }
@@ -72,9 +73,9 @@ extern "C" size_t mio_fused_mlp_workspace_bytes(int64_t M, int32_t d, int32_t I,
   return (size_t)mp * (size_t)I * 2;
 }
 
-extern "C" int mio_fused_mlp_fwd(const void* x, const void* w1, const void* b1, const void* wg, const void* bg,
-                                 const void* w2, const void* b2, const void* residual, void* y, void* workspace,
-                                 int64_t M, int32_t d, int32_t I, int32_t act, int32_t dtype, void* stream) {
+static int fused_mlp_impl(const void* x, const void* w1, const void* b1, const void* wg, const void* bg, const void* w2,
+                          const void* b2, const void* residual, void* y, void* workspace, int64_t M, int32_t d, int32_t I,
+                          int32_t act, int32_t dtype, void* stream, int wblk) {
   MIO_CHECK(workspace != nullptr || M == 0, "mio_fused_mlp_fwd: workspace must be non-null");
   MIO_CHECK(act != MIO_ACT_NONE, "mio_fused_mlp_fwd: an activation is required");
   if (M > 0 && mlp_blocked_ok(M, d, I, act, residual != nullptr)) {
@@ -87,7 +88,7 @@ extern "C" int mio_fused_mlp_fwd(const void* x, const void* w1, const void* b1, 
     p.x = x; p.w = w1; p.wg = nullptr; p.bias = b1; p.bias_g = nullptr; p.res = nullptr; p.y = workspace;
     p.M = M; p.ldx = d; p.ldw = d; p.ldy = I; p.ldr = 0; p.N = I; p.K = d;
     p.tiles_m = p.tiles_n = 0;
-    p.x_blk = 0; p.y_blk = 1;
+    p.x_blk = 0; p.y_blk = 1; p.w_blk = wblk;
     p.dbg = nullptr;
     int rc = gemm_dispatch(p, act, dtype, (hipStream_t)stream);
     if (rc != 0) return rc;
@@ -97,10 +98,94 @@ extern "C" int mio_fused_mlp_fwd(const void* x, const void* w1, const void* b1, 
     p.x_blk = 1; p.y_blk = 0;
     return gemm_dispatch(p, MIO_ACT_NONE, dtype, (hipStream_t)stream);
   }
+  MIO_CHECK(!wblk, "mio_fused_mlp_fwd_bw: this shape does not take the blocked-weight kernels "
+                   "(mio_fused_mlp_blocked_weight_ok == 0); pass the plain weights to mio_fused_mlp_fwd");
   // stage 1: h = act(x w1^T + b1) [* silu-gate], written once in the storage dtype
   int rc = mio_gemm_bias_act(x, w1, b1, wg, bg, nullptr, workspace, M, I, d, d, d, I, 0, act, dtype, stream);
   if (rc != 0) return rc;
   // stage 2: y = h w2^T + b2 (+ residual)
   return mio_gemm_bias_act(workspace, w2, b2, nullptr, nullptr, residual, y, M, d, I, I, I, d, d, MIO_ACT_NONE,
                            dtype, stream);
+}
+
+extern "C" int mio_fused_mlp_fwd(const void* x, const void* w1, const void* b1, const void* wg, const void* bg,
+                                 const void* w2, const void* b2, const void* residual, void* y, void* workspace,
+                                 int64_t M, int32_t d, int32_t I, int32_t act, int32_t dtype, void* stream) {
+  return fused_mlp_impl(x, w1, b1, wg, bg, w2, b2, residual, y, workspace, M, d, I, act, dtype, stream, 0);
+}
+
+// ---- blocked weights -----------------------------------------------------------------------------------------------
+static bool gemm_blocked_w_ok(int64_t M, int32_t N, int32_t K, int32_t act) {
+  if (act == MIO_ACT_SWIGLU || (mio_gemm_impl() != 0 && mio_gemm_impl() < 5)) return false;
+  const bool big = ((M + 255) / 256) * (int64_t)((N + 255) / 256) >= 256;
+  return big && K % 32 == 0 && (int64_t)K * 512 < 0x7fffffff;
+}
+
+extern "C" size_t mio_weight_blocked_bytes(int32_t N, int32_t K) {
+  return (size_t)((N + 255) / 256 * 256) * (size_t)K * 2;
+}
+
+// one 16-byte chunk per thread: destination unit u = ((tn * nk + kt) * 256 + row) * 4 + chunk
+__global__ void weight_block_kernel(const uint16_t* __restrict__ w, int64_t ldw, uint16_t* __restrict__ wb, int N, int K,
+                                    int64_t units) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= units) return;
+  const int nk = K / 32;
+  const int chunk = (int)(u & 3), row = (int)((u >> 2) & 255);
+  const int64_t blk = u >> 10;
+  const int kt = (int)(blk % nk), tn = (int)(blk / nk);
+  const int n = tn * 256 + row;
+  u32x4_t v = {0u, 0u, 0u, 0u};
+  if (n < N) v = *(const u32x4_t*)(w + (int64_t)n * ldw + kt * 32 + chunk * 8);
+  *(u32x4_t*)(wb + u * 8) = v;
+}
+
+extern "C" int mio_weight_block(const void* w, int64_t ldw, void* wb, int32_t N, int32_t K, int32_t dtype, void* stream) {
+  MIO_CHECK(w && wb, "mio_weight_block: w and wb must be non-null");
+  MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_weight_block: dtype must be bf16 or fp16");
+  MIO_CHECK(N > 0 && K > 0 && K % 32 == 0 && ldw >= K && ldw % 8 == 0, "mio_weight_block: need K % 32 == 0, ldw % 8 == 0");
+  MIO_CHECK(mio_aligned16(w) && mio_aligned16(wb), "mio_weight_block: pointers must be 16-byte aligned");
+  const int64_t units = (int64_t)((N + 255) / 256) * (K / 32) * 1024;
+  hipLaunchKernelGGL(weight_block_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)w, ldw, (uint16_t*)wb, N, K, units);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("mio_weight_block launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int32_t mio_gemm_blocked_weight_ok(int64_t M, int32_t N, int32_t K, int32_t act) {
+  return gemm_blocked_w_ok(M, N, K, act) ? 1 : 0;
+}
+
+extern "C" int mio_gemm_bias_act_bw(const void* x, const void* wb, const void* bias, const void* residual, void* y,
+                                    int64_t M, int32_t N, int32_t K, int64_t ldx, int64_t ldy, int64_t ldr, int32_t act,
+                                    int32_t dtype, void* stream) {
+  MIO_CHECK(x && wb && y, "mio_gemm_bias_act_bw: x, wb, y must be non-null");
+  MIO_CHECK(M >= 0 && N > 0 && K > 0, "mio_gemm_bias_act_bw: bad sizes");
+  MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_gemm_bias_act_bw: dtype must be bf16 or fp16");
+  MIO_CHECK(act >= MIO_ACT_NONE && act < MIO_ACT_SWIGLU, "mio_gemm_bias_act_bw: unknown / unsupported activation");
+  MIO_CHECK(N % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (residual == nullptr || ldr % 8 == 0) && ldx >= K && ldy >= N,
+            "mio_gemm_bias_act_bw: bad strides");
+  MIO_CHECK(mio_aligned16(x) && mio_aligned16(wb) && mio_aligned16(y) && mio_aligned16(residual) && mio_aligned16(bias),
+            "mio_gemm_bias_act_bw: pointers must be 16-byte aligned");
+  MIO_CHECK(ldx * 512 < (int64_t)0x7fffffff, "mio_gemm_bias_act_bw: ldx too large for the blocked-weight kernels");
+  MIO_CHECK(gemm_blocked_w_ok(M, N, K, act), "mio_gemm_bias_act_bw: this shape does not take the blocked-weight kernels "
+                                             "(mio_gemm_blocked_weight_ok == 0); use mio_gemm_bias_act with the plain weight");
+  GemmDev p;
+  p.x = x; p.w = wb; p.wg = nullptr; p.bias = bias; p.bias_g = nullptr; p.res = residual; p.y = y;
+  p.M = M; p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.ldr = ldr; p.N = N; p.K = K;
+  p.tiles_m = p.tiles_n = 0;
+  p.x_blk = p.y_blk = 0; p.w_blk = 1;
+  p.dbg = nullptr;
+  return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
+}
+
+extern "C" int32_t mio_fused_mlp_blocked_weight_ok(int64_t M, int32_t d, int32_t I, int32_t act) {
+  return (M > 0 && mlp_blocked_ok(M, d, I, act, false)) ? 1 : 0;
+}
+
+extern "C" int mio_fused_mlp_fwd_bw(const void* x, const void* w1b, const void* b1, const void* w2b, const void* b2,
+                                    const void* residual, void* y, void* workspace, int64_t M, int32_t d, int32_t I,
+                                    int32_t act, int32_t dtype, void* stream) {
+  return fused_mlp_impl(x, w1b, b1, nullptr, nullptr, w2b, b2, residual, y, workspace, M, d, I, act, dtype, stream, 1);
 }

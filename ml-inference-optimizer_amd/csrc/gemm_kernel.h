@@ -34,6 +34,8 @@ struct GemmDev {
   // the consuming GEMM is one contiguous 16 KiB block.  With the plain [M, I] layout a K-tile is 256 pieces of 64 B
   // at a stride of 2 I bytes: at I = 4096 that access pattern, not the matrix pipe, bounds the second GEMM.
   int x_blk, y_blk;
+  // Blocked weight (mio_weight_block, one-time repack): the same layout with n in the place of m, rows padded to 256.
+  int w_blk;
   unsigned long long* dbg;  // diagnostic builds only (in-kernel stamps); nullptr otherwise
 };
 

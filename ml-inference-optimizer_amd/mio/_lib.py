@@ -30,6 +30,12 @@ EXPORTS = (
     "mio_gemm_bias_act",
     "mio_fused_mlp_workspace_bytes",
     "mio_fused_mlp_fwd",
+    "mio_weight_blocked_bytes",
+    "mio_weight_block",
+    "mio_gemm_blocked_weight_ok",
+    "mio_gemm_bias_act_bw",
+    "mio_fused_mlp_blocked_weight_ok",
+    "mio_fused_mlp_fwd_bw",
     "mio_layernorm_fwd",
     "mio_fa3_decode_workspace_bytes",
     "mio_fa3_decode_paged",
@@ -92,6 +98,18 @@ def _load() -> C.CDLL:
     lib.mio_fused_mlp_workspace_bytes.restype = C.c_size_t
     lib.mio_fused_mlp_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
     lib.mio_fused_mlp_fwd.restype = i32
+    lib.mio_weight_blocked_bytes.argtypes = [i32, i32]
+    lib.mio_weight_blocked_bytes.restype = C.c_size_t
+    lib.mio_weight_block.argtypes = [vp, i64, vp, i32, i32, i32, vp]
+    lib.mio_weight_block.restype = i32
+    lib.mio_gemm_blocked_weight_ok.argtypes = [i64, i32, i32, i32]
+    lib.mio_gemm_blocked_weight_ok.restype = i32
+    lib.mio_gemm_bias_act_bw.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i32, i32, vp]
+    lib.mio_gemm_bias_act_bw.restype = i32
+    lib.mio_fused_mlp_blocked_weight_ok.argtypes = [i64, i32, i32, i32]
+    lib.mio_fused_mlp_blocked_weight_ok.restype = i32
+    lib.mio_fused_mlp_fwd_bw.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+    lib.mio_fused_mlp_fwd_bw.restype = i32
     lib.mio_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]
     lib.mio_layernorm_fwd.restype = i32
     lib.mio_fa3_decode_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]

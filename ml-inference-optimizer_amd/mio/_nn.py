@@ -36,7 +36,7 @@ class CastCache:
     whose parameters are stored in another dtype does not re-cast them on every forward."""
 
     def __init__(self):
-        self._c: Dict[int, Tuple[Tuple, torch.Tensor]] = {}
+        self._c: Dict[object, Tuple[Tuple, torch.Tensor]] = {}
 
     def get(self, p: Optional[torch.Tensor], dtype: torch.dtype) -> Optional[torch.Tensor]:
         if p is None:
@@ -51,9 +51,23 @@ class CastCache:
         self._c[id(p)] = (key, t)
         return t
 
+    def get_blocked(self, p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        """The parameter in the blocked weight layout (ops.block_weight), repacked when its version changes."""
+        key = (p.data_ptr(), p._version, dtype, p.device, "blocked")
+        hit = self._c.get(("b", id(p)))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        t = ops.block_weight(self.get(p, dtype))
+        self._c[("b", id(p))] = (key, t)
+        return t
+
 
 def linear(x: torch.Tensor, lin: nn.Linear, cache: CastCache, dtype: torch.dtype, activation: str = "none",
            residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """F.linear(x, W, b) (+ activation, + residual) on the MFMA GEMM."""
-    return ops.gemm_bias_act(x, cache.get(lin.weight, dtype), cache.get(lin.bias, dtype), activation,
-                             residual=residual)
+    """F.linear(x, W, b) (+ activation, + residual) on the MFMA GEMM.  At sizes that run the 256x256-tile kernels the
+    weight is handed over in the blocked layout (repacked once per parameter version, cached next to the cast copy)."""
+    w = cache.get(lin.weight, dtype)
+    N, K = w.shape
+    M = x.numel() // K
+    wb = cache.get_blocked(lin.weight, dtype) if (K % 32 == 0 and ops.blocked_weight_ok(M, N, K, activation)) else None
+    return ops.gemm_bias_act(x, w, cache.get(lin.bias, dtype), activation, residual=residual, w_blocked=wb)

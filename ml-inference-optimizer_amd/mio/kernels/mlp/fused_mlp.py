@@ -72,8 +72,12 @@ class FusedMLP(nn.Module):
         r = None if residual is None else (residual if residual.dtype == dt else residual.to(dt))
         c = self._cast
         gw, gb = self._gate(dt)
+        M, d, I = x.numel() // x.shape[-1], x.shape[-1], self.fc1.weight.shape[0]
+        b1 = b2 = None  # blocked weight copies, when this shape runs the kernels that take them
+        if gw is None and ops.fused_mlp_blocked_weight_ok(M, d, I, act):
+            b1, b2 = c.get_blocked(self.fc1.weight, dt), c.get_blocked(self.fc2.weight, dt)
         out = ops.fused_mlp(x, c.get(self.fc1.weight, dt), c.get(self.fc1.bias, dt), c.get(self.fc2.weight, dt),
-                            c.get(self.fc2.bias, dt), act, gw, gb, residual=r)
+                            c.get(self.fc2.bias, dt), act, gw, gb, residual=r, fc1_blocked=b1, fc2_blocked=b2)
         return out if out.dtype == in_dtype else out.to(in_dtype)
 
 

@@ -12,6 +12,8 @@ There is no fallback path: a non-zero return from the library raises RuntimeErro
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from typing import Optional, Tuple
@@ -247,7 +249,36 @@ def attn_merge(o_a, lse_a, o_b, lse_b, out: Optional[torch.Tensor] = None):
 # ------------------------------------------------------------------------------------------------
 # GEMM / FusedMLP / LayerNorm
 # ------------------------------------------------------------------------------------------------
-def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_gate=None, residual=None, out=None):
+_NO_BLOCKED_W = os.environ.get("MIO_NO_BLOCKED_W", "0") == "1"
+
+
+def block_weight(w: torch.Tensor) -> torch.Tensor:
+    """One-time repack of a Linear weight [N, K] (K % 32 == 0) into the blocked layout of include/mio_hip.h
+    (contiguous 16 KiB K-tiles): returns a [ceil(N/256)*256, K] tensor holding the blocked bytes."""
+    _need_cuda(w)
+    if w.dim() != 2 or w.shape[1] % 32 != 0:
+        raise ValueError(f"block_weight needs a 2-D weight with K % 32 == 0, got {tuple(w.shape)}")
+    w = _rows16(w)
+    N, K = w.shape
+    wb = torch.empty((N + 255) // 256 * 256, K, dtype=w.dtype, device=w.device)
+    assert wb.numel() * wb.element_size() == lib.mio_weight_blocked_bytes(N, K)
+    check(lib.mio_weight_block(w.data_ptr(), w.stride(0), wb.data_ptr(), N, K, _dtype_id(w), _stream()))
+    return wb
+
+
+def blocked_weight_ok(M: int, N: int, K: int, activation: str = "none") -> bool:
+    """True iff a GEMM of this shape runs a kernel that takes blocked weights (w_blocked= below).
+    MIO_NO_BLOCKED_W=1 (A/B runs) keeps the modules on the plain weights."""
+    return not _NO_BLOCKED_W and bool(lib.mio_gemm_blocked_weight_ok(M, N, K, _ACT.get(activation, _lib.ACT_NONE)))
+
+
+def fused_mlp_blocked_weight_ok(M: int, d: int, I: int, activation: str) -> bool:
+    """True iff ops.fused_mlp at this shape takes blocked fc1 / fc2 weights (fc1_blocked= / fc2_blocked=)."""
+    return not _NO_BLOCKED_W and bool(lib.mio_fused_mlp_blocked_weight_ok(M, d, I, _ACT.get(activation, _lib.ACT_NONE)))
+
+
+def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_gate=None, residual=None, out=None,
+                  w_blocked=None):
     """y = act(x @ w^T + bias) (+ residual); x [..., K], w [N, K].  F.linear with a fused epilogue."""
     _need_cuda(x, w)
     if activation not in _ACT:
@@ -278,6 +309,11 @@ def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_g
     for b_ in (bias, bias_gate):
         if b_ is not None and (b_.dtype != x.dtype or not b_.is_contiguous()):
             raise ValueError("bias must be contiguous and of the input dtype")
+    if w_blocked is not None and act != _lib.ACT_SWIGLU and lib.mio_gemm_blocked_weight_ok(M, N, K, act) and \
+            x2.stride(0) * 512 < 0x7fffffff:
+        check(lib.mio_gemm_bias_act_bw(x2.data_ptr(), w_blocked.data_ptr(), _ptr(bias), _ptr(r2), y2.data_ptr(), M, N, K,
+                                       x2.stride(0), y2.stride(0), 0 if r2 is None else r2.stride(0), act, dt, _stream()))
+        return out
     check(lib.mio_gemm_bias_act(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(w_gate), _ptr(bias_gate), _ptr(r2),
                                 y2.data_ptr(), M, N, K, x2.stride(0), w.stride(0), y2.stride(0),
                                 0 if r2 is None else r2.stride(0), act, dt, _stream()))
@@ -294,6 +330,8 @@ def fused_mlp(
     fc1_gate_weight: Optional[torch.Tensor] = None,
     fc1_gate_bias: Optional[torch.Tensor] = None,
     residual: Optional[torch.Tensor] = None,
+    fc1_blocked: Optional[torch.Tensor] = None,
+    fc2_blocked: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """Drop-in for triton_fused_mlp (mlp_kernels.py:648-756): fc2(act(fc1(x))), hidden [B,S,d].
     "gelu" is the tanh form like the Triton kernel (:144-161); "gelu_erf" is pytorch_fused_mlp's (:782-783)."""
@@ -328,6 +366,11 @@ def fused_mlp(
             r2 = r2.contiguous()
     gate_w = fc1_gate_weight if act == _lib.ACT_SWIGLU else None
     gate_b = fc1_gate_bias if act == _lib.ACT_SWIGLU else None
+    if fc1_blocked is not None and fc2_blocked is not None and lib.mio_fused_mlp_blocked_weight_ok(M, d, I, act):
+        check(lib.mio_fused_mlp_fwd_bw(x2.data_ptr(), fc1_blocked.data_ptr(), _ptr(fc1_bias), fc2_blocked.data_ptr(),
+                                       _ptr(fc2_bias), _ptr(r2), out.data_ptr(), work.data_ptr(), M, d, I, act, dt,
+                                       _stream()))
+        return out
     check(lib.mio_fused_mlp_fwd(x2.data_ptr(), fc1_weight.data_ptr(), _ptr(fc1_bias), _ptr(gate_w), _ptr(gate_b),
                                 fc2_weight.data_ptr(), _ptr(fc2_bias), _ptr(r2), out.data_ptr(), work.data_ptr(),
                                 M, d, I, act, dt, _stream()))

@@ -299,6 +299,11 @@ def test_fused_mlp_blocked_intermediate(dtype, act, res, M):
         ref = ref + r[0].double()
     rel = ((y[0].float().cpu().double() - ref).abs().mean() / ref.abs().mean()).item()
     assert rel < (2e-3 if dtype == torch.float16 else 1e-2), f"rel_err={rel:.3e}"
+    assert ops.fused_mlp_blocked_weight_ok(M, d, I, act)
+    y2 = ops.fused_mlp(x.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), act,
+                       residual=None if r is None else r.to(DEV),
+                       fc1_blocked=ops.block_weight(w1.to(DEV)), fc2_blocked=ops.block_weight(w2.to(DEV)))
+    assert torch.equal(y2, y)  # blocked weights: same kernels, same arithmetic
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -329,6 +334,17 @@ def test_gemm_big_tiles(dtype, M, N, K, act, res):
     if r is not None:
         z = z + r.double()
     _cmp(y, z, dtype, f"gemm {M}x{N}x{K} {act} res={res}")
+    if K % 32 == 0:  # the same launch with the weight in the blocked layout: same kernel, same arithmetic -> same bits
+        assert ops.blocked_weight_ok(M, N, K, act)
+        wb = ops.block_weight(w.to(DEV))
+        ref_blk = w.view(-1)  # layout check against the definition: wb[((n/256)*(K/32) + k/32)*256 + n%256][k%32]
+        Np = (N + 255) // 256 * 256
+        wp = torch.zeros(Np, K, dtype=dtype)
+        wp[:N] = w
+        want = wp.view(Np // 256, 256, K // 32, 32).permute(0, 2, 1, 3).reshape(Np, K)
+        assert torch.equal(wb.cpu(), want)
+        y2 = ops.gemm_bias_act(x.to(DEV), w.to(DEV), b.to(DEV), act, residual=None if r is None else r.to(DEV), w_blocked=wb)
+        assert torch.equal(y2, y)
 
 
 def test_gemm_big_tiles_exact():
