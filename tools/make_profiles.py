@@ -31,8 +31,9 @@ def short(name):
             return f"{k}<{dt},{ACT.get(vals[-1], vals[-1])}>"
         if k in ("fa3_fwd_kernel", "fa3_fwd2_kernel"):
             return f"{k}<{dt},D{vals[0]},{'causal' if vals[1] == '1' else 'full'}>"
-        if k == "fa3_fwd3_kernel":
-            return f"{k}<{dt},{'causal' if vals[0] == '1' else 'full'}>"
+        if k == "fa3_fwd3_kernel":  # <T, D, CAUSAL, STAMP>; the benchmark's head dim 64 keeps the short name bench.py uses
+            tag = "" if vals[0] == "64" else f"D{vals[0]},"
+            return f"{k}<{dt},{tag}{'causal' if vals[1] == '1' else 'full'}>"
         return f"{k}<{dt}>"
     if re.match(r"(?:void )?fa3_fwd3_kernel<bool _Accum, bool, E", name):  # <__bf16, true, false> mis-demangled
         return "fa3_fwd3_kernel<bf16,causal>"
