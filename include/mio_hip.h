@@ -139,11 +139,15 @@ int mio_weight_block(const void* w, int64_t ldw, void* wb, int32_t N, int32_t K,
 int32_t mio_gemm_blocked_weight_ok(int64_t M, int32_t N, int32_t K, int32_t act);
 int mio_gemm_bias_act_bw(const void* x, const void* wb, const void* bias, const void* residual, void* y, int64_t M,
                          int32_t N, int32_t K, int64_t ldx, int64_t ldy, int64_t ldr, int32_t act, int32_t dtype,
-                         void* stream);
+                         int32_t x_blocked, void* stream);
 int32_t mio_fused_mlp_blocked_weight_ok(int64_t M, int32_t d, int32_t I, int32_t act);
 int mio_fused_mlp_fwd_bw(const void* x, const void* w1b, const void* b1, const void* w2b, const void* b2,
                          const void* residual, void* y, void* workspace, int64_t M, int32_t d, int32_t I, int32_t act,
-                         int32_t dtype, void* stream);
+                         int32_t dtype, int32_t x_blocked, void* stream);
+/* x_blocked != 0: the activation operand x is in the same blocked layout (m in the place of n; ceil(M/256)*256 x K
+ * elements, ldx ignored) -- what mio_layernorm_fwd_bx writes, so that LayerNorm -> GEMM hands over contiguous K-tiles. */
+int mio_layernorm_fwd_bx(const void* x, const void* residual, const void* weight, const void* bias, void* yb,
+                         void* sum_out, int64_t rows, int32_t cols, float eps, float alpha, int32_t dtype, void* stream);
 
 /* LayerNorm / residual+LayerNorm rows (the step either side of attention):
  * sum = x + alpha*residual (if residual), y = (sum-mean)/sqrt(var+eps)*weight + bias.

@@ -75,7 +75,7 @@ extern "C" size_t mio_fused_mlp_workspace_bytes(int64_t M, int32_t d, int32_t I,
 
 static int fused_mlp_impl(const void* x, const void* w1, const void* b1, const void* wg, const void* bg, const void* w2,
                           const void* b2, const void* residual, void* y, void* workspace, int64_t M, int32_t d, int32_t I,
-                          int32_t act, int32_t dtype, void* stream, int wblk) {
+                          int32_t act, int32_t dtype, void* stream, int wblk, int xblk = 0) {
   MIO_CHECK(workspace != nullptr || M == 0, "mio_fused_mlp_fwd: workspace must be non-null");
   MIO_CHECK(act != MIO_ACT_NONE, "mio_fused_mlp_fwd: an activation is required");
   if (M > 0 && mlp_blocked_ok(M, d, I, act, residual != nullptr)) {
@@ -88,7 +88,7 @@ static int fused_mlp_impl(const void* x, const void* w1, const void* b1, const v
     p.x = x; p.w = w1; p.wg = nullptr; p.bias = b1; p.bias_g = nullptr; p.res = nullptr; p.y = workspace;
     p.M = M; p.ldx = d; p.ldw = d; p.ldy = I; p.ldr = 0; p.N = I; p.K = d;
     p.tiles_m = p.tiles_n = 0;
-    p.x_blk = 0; p.y_blk = 1; p.w_blk = wblk;
+    p.x_blk = xblk; p.y_blk = 1; p.w_blk = wblk;
     p.dbg = nullptr;
     int rc = gemm_dispatch(p, act, dtype, (hipStream_t)stream);
     if (rc != 0) return rc;
@@ -98,7 +98,7 @@ static int fused_mlp_impl(const void* x, const void* w1, const void* b1, const v
     p.x_blk = 1; p.y_blk = 0;
     return gemm_dispatch(p, MIO_ACT_NONE, dtype, (hipStream_t)stream);
   }
-  MIO_CHECK(!wblk, "mio_fused_mlp_fwd_bw: this shape does not take the blocked-weight kernels "
+  MIO_CHECK(!wblk && !xblk, "mio_fused_mlp_fwd_bw: this shape does not take the blocked-weight kernels "
                    "(mio_fused_mlp_blocked_weight_ok == 0); pass the plain weights to mio_fused_mlp_fwd");
   // stage 1: h = act(x w1^T + b1) [* silu-gate], written once in the storage dtype
   int rc = mio_gemm_bias_act(x, w1, b1, wg, bg, nullptr, workspace, M, I, d, d, d, I, 0, act, dtype, stream);
@@ -159,11 +159,12 @@ extern "C" int32_t mio_gemm_blocked_weight_ok(int64_t M, int32_t N, int32_t K, i
 
 extern "C" int mio_gemm_bias_act_bw(const void* x, const void* wb, const void* bias, const void* residual, void* y,
                                     int64_t M, int32_t N, int32_t K, int64_t ldx, int64_t ldy, int64_t ldr, int32_t act,
-                                    int32_t dtype, void* stream) {
+                                    int32_t dtype, int32_t x_blocked, void* stream) {
   MIO_CHECK(x && wb && y, "mio_gemm_bias_act_bw: x, wb, y must be non-null");
   MIO_CHECK(M >= 0 && N > 0 && K > 0, "mio_gemm_bias_act_bw: bad sizes");
   MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_gemm_bias_act_bw: dtype must be bf16 or fp16");
   MIO_CHECK(act >= MIO_ACT_NONE && act < MIO_ACT_SWIGLU, "mio_gemm_bias_act_bw: unknown / unsupported activation");
+  if (x_blocked) ldx = K;  // blocked x: ceil(M / 256) * 256 x K elements, no row stride
   MIO_CHECK(N % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (residual == nullptr || ldr % 8 == 0) && ldx >= K && ldy >= N,
             "mio_gemm_bias_act_bw: bad strides");
   MIO_CHECK(mio_aligned16(x) && mio_aligned16(wb) && mio_aligned16(y) && mio_aligned16(residual) && mio_aligned16(bias),
@@ -175,7 +176,7 @@ extern "C" int mio_gemm_bias_act_bw(const void* x, const void* wb, const void* b
   p.x = x; p.w = wb; p.wg = nullptr; p.bias = bias; p.bias_g = nullptr; p.res = residual; p.y = y;
   p.M = M; p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.ldr = ldr; p.N = N; p.K = K;
   p.tiles_m = p.tiles_n = 0;
-  p.x_blk = p.y_blk = 0; p.w_blk = 1;
+  p.x_blk = x_blocked ? 1 : 0; p.y_blk = 0; p.w_blk = 1;
   p.dbg = nullptr;
   return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
 }
@@ -186,6 +187,7 @@ extern "C" int32_t mio_fused_mlp_blocked_weight_ok(int64_t M, int32_t d, int32_t
 
 extern "C" int mio_fused_mlp_fwd_bw(const void* x, const void* w1b, const void* b1, const void* w2b, const void* b2,
                                     const void* residual, void* y, void* workspace, int64_t M, int32_t d, int32_t I,
-                                    int32_t act, int32_t dtype, void* stream) {
-  return fused_mlp_impl(x, w1b, b1, nullptr, nullptr, w2b, b2, residual, y, workspace, M, d, I, act, dtype, stream, 1);
+                                    int32_t act, int32_t dtype, int32_t x_blocked, void* stream) {
+  return fused_mlp_impl(x, w1b, b1, nullptr, nullptr, w2b, b2, residual, y, workspace, M, d, I, act, dtype, stream, 1,
+                        x_blocked ? 1 : 0);
 }

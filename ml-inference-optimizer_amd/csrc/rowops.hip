@@ -29,7 +29,7 @@ template <typename T, int CH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                         const T* __restrict__ w, const T* __restrict__ bias,
                                                         T* __restrict__ y, T* __restrict__ sum_out, int64_t rows,
-                                                        int cols, float eps, float alpha) {
+                                                        int cols, float eps, float alpha, int yblk) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -83,19 +83,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
       if (bias != nullptr) unpack8<T>(*(const u32x4_t*)(bias + 8 * c), bv);
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = (v[j][i] - mean) * rstd * wv[i] + (bias != nullptr ? bv[i] : 0.f);
-      *(u32x4_t*)(y + row * cols + 8 * c) = pack8<T>(o);
+      // yblk: blocked activation layout (gemm_kernel.h GemmDev::x_blk): chunk c of the row is chunk c & 3 of the 64-byte
+      // row segment in K-tile block c >> 2
+      const int64_t yo = yblk ? (((row >> 8) * (cols >> 5) + (c >> 2)) * 256 + (row & 255)) * 32 + (c & 3) * 8
+                              : row * cols + 8 * c;
+      *(u32x4_t*)(y + yo) = pack8<T>(o);
     }
   }
 }
 
 template <typename T>
 static int ln_launch(const void* x, const void* res, const void* w, const void* b, void* y, void* sum_out, int64_t rows,
-                     int cols, float eps, float alpha, hipStream_t st) {
+                     int cols, float eps, float alpha, hipStream_t st, int yblk) {
   const int nch = cols / 8;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define LN_GO(CH)                                                                                             \
   hipLaunchKernelGGL((layernorm_kernel<T, CH>), grid, block, 0, st, (const T*)x, (const T*)res, (const T*)w, \
-                     (const T*)b, (T*)y, (T*)sum_out, rows, cols, eps, alpha)
+                     (const T*)b, (T*)y, (T*)sum_out, rows, cols, eps, alpha, yblk)
   if (nch <= 64) LN_GO(1);
   else if (nch <= 128) LN_GO(2);
   else if (nch <= 256) LN_GO(4);
@@ -107,19 +111,34 @@ static int ln_launch(const void* x, const void* res, const void* w, const void* 
   return 0;
 }
 
-extern "C" int mio_layernorm_fwd(const void* x, const void* residual, const void* weight, const void* bias, void* y,
-                                 void* sum_out, int64_t rows, int32_t cols, float eps, float alpha, int32_t dtype,
-                                 void* stream) {
+static int ln_entry(const char* who, const void* x, const void* residual, const void* weight, const void* bias, void* y,
+                    void* sum_out, int64_t rows, int32_t cols, float eps, float alpha, int32_t dtype, void* stream, int yblk) {
+  (void)who;
   MIO_CHECK(x && weight && y, "mio_layernorm_fwd: x, weight, y must be non-null");
   MIO_CHECK(rows >= 0 && cols > 0 && cols % 8 == 0, "mio_layernorm_fwd: cols must be a positive multiple of 8");
+  MIO_CHECK(!yblk || cols % 32 == 0, "mio_layernorm_fwd_bx: cols must be a multiple of 32");
   MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_layernorm_fwd: dtype must be bf16 or fp16");
   MIO_CHECK(mio_aligned16(x) && mio_aligned16(residual) && mio_aligned16(weight) && mio_aligned16(bias) &&
                 mio_aligned16(y) && mio_aligned16(sum_out),
             "mio_layernorm_fwd: pointers must be 16-byte aligned");
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MIO_BF16) return ln_launch<__bf16>(x, residual, weight, bias, y, sum_out, rows, cols, eps, alpha, st);
-  return ln_launch<_Float16>(x, residual, weight, bias, y, sum_out, rows, cols, eps, alpha, st);
+  if (dtype == MIO_BF16)
+    return ln_launch<__bf16>(x, residual, weight, bias, y, sum_out, rows, cols, eps, alpha, st, yblk);
+  return ln_launch<_Float16>(x, residual, weight, bias, y, sum_out, rows, cols, eps, alpha, st, yblk);
+}
+
+extern "C" int mio_layernorm_fwd(const void* x, const void* residual, const void* weight, const void* bias, void* y,
+                                 void* sum_out, int64_t rows, int32_t cols, float eps, float alpha, int32_t dtype,
+                                 void* stream) {
+  return ln_entry("mio_layernorm_fwd", x, residual, weight, bias, y, sum_out, rows, cols, eps, alpha, dtype, stream, 0);
+}
+
+// y in the blocked activation layout (include/mio_hip.h): ceil(rows / 256) * 256 x cols elements
+extern "C" int mio_layernorm_fwd_bx(const void* x, const void* residual, const void* weight, const void* bias, void* yb,
+                                    void* sum_out, int64_t rows, int32_t cols, float eps, float alpha, int32_t dtype,
+                                    void* stream) {
+  return ln_entry("mio_layernorm_fwd_bx", x, residual, weight, bias, yb, sum_out, rows, cols, eps, alpha, dtype, stream, 1);
 }
 
 // ---- merge of two normalised partial attention states ------------------------------------------

@@ -36,6 +36,7 @@ EXPORTS = (
     "mio_gemm_bias_act_bw",
     "mio_fused_mlp_blocked_weight_ok",
     "mio_fused_mlp_fwd_bw",
+    "mio_layernorm_fwd_bx",
     "mio_layernorm_fwd",
     "mio_fa3_decode_workspace_bytes",
     "mio_fa3_decode_paged",
@@ -104,14 +105,16 @@ def _load() -> C.CDLL:
     lib.mio_weight_block.restype = i32
     lib.mio_gemm_blocked_weight_ok.argtypes = [i64, i32, i32, i32]
     lib.mio_gemm_blocked_weight_ok.restype = i32
-    lib.mio_gemm_bias_act_bw.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i32, i32, vp]
+    lib.mio_gemm_bias_act_bw.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i32, i32, i32, vp]
     lib.mio_gemm_bias_act_bw.restype = i32
     lib.mio_fused_mlp_blocked_weight_ok.argtypes = [i64, i32, i32, i32]
     lib.mio_fused_mlp_blocked_weight_ok.restype = i32
-    lib.mio_fused_mlp_fwd_bw.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+    lib.mio_fused_mlp_fwd_bw.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]
     lib.mio_fused_mlp_fwd_bw.restype = i32
     lib.mio_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]
     lib.mio_layernorm_fwd.restype = i32
+    lib.mio_layernorm_fwd_bx.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]
+    lib.mio_layernorm_fwd_bx.restype = i32
     lib.mio_fa3_decode_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     lib.mio_fa3_decode_workspace_bytes.restype = C.c_size_t
     lib.mio_fa3_decode_paged.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64), i32, i32, i32, i32,

@@ -71,3 +71,18 @@ def linear(x: torch.Tensor, lin: nn.Linear, cache: CastCache, dtype: torch.dtype
     M = x.numel() // K
     wb = cache.get_blocked(lin.weight, dtype) if (K % 32 == 0 and ops.blocked_weight_ok(M, N, K, activation)) else None
     return ops.gemm_bias_act(x, w, cache.get(lin.bias, dtype), activation, residual=residual, w_blocked=wb)
+
+
+def prenorm_linear(x: torch.Tensor, ln: nn.LayerNorm, lin: nn.Linear, cache: CastCache, dtype: torch.dtype,
+                   activation: str = "none", residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """lin(ln(x)) (+ activation, + residual).  At sizes that run the 256x256-tile kernels LayerNorm writes its output in
+    the blocked activation layout, so the GEMM's K-tile fetches are contiguous on both operands."""
+    w = cache.get(lin.weight, dtype)
+    N, K = w.shape
+    M = x.numel() // K
+    lw, lb = cache.get(ln.weight, dtype), cache.get(ln.bias, dtype)
+    if K % 32 == 0 and not ops.NO_BLOCKED_X and ops.blocked_weight_ok(M, N, K, activation):
+        xb = ops.layernorm(x, lw, lb, ln.eps, out_blocked=True)
+        return ops.gemm_bias_act(xb, w, cache.get(lin.bias, dtype), activation, residual=residual,
+                                 w_blocked=cache.get_blocked(lin.weight, dtype), x_blocked_shape=tuple(x.shape))
+    return linear(ops.layernorm(x, lw, lb, ln.eps), lin, cache, dtype, activation, residual)

@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ..._nn import CastCache, compute_dtype, linear
+from ..._nn import CastCache, compute_dtype, linear, prenorm_linear
 
 
 @dataclass
@@ -187,7 +187,10 @@ class FlashSelfAttention(_AttentionBase):
             nn.init.zeros_(lin.bias)
 
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                residual: Optional[torch.Tensor] = None, **kwargs: Any) -> torch.Tensor:
+                residual: Optional[torch.Tensor] = None, pre_norm: Optional[nn.LayerNorm] = None,
+                **kwargs: Any) -> torch.Tensor:
+        """pre_norm (not in the reference): a LayerNorm to apply to hidden_states first -- the pre-LN block's
+        `attn(ln(x))` in one call, which lets LayerNorm hand its output to the QKV GEMM in the blocked layout."""
         if hidden_states.dim() != 3:
             raise ValueError(f"Expected 3D input tensor, got shape: {hidden_states.shape}")
         if not hidden_states.is_cuda:
@@ -199,6 +202,9 @@ class FlashSelfAttention(_AttentionBase):
         r = None if residual is None else (residual if residual.dtype == dt else residual.to(dt))
         c = self._cast
         q_dim, kv_dim = self.hidden_size, self.num_kv_heads * self.head_dim
+        if pre_norm is not None and "block_tables" in kwargs:
+            x = ops.layernorm(x, c.get(pre_norm.weight, dt), c.get(pre_norm.bias, dt), pre_norm.eps)
+            pre_norm = None
         if "block_tables" in kwargs:
             # only the query slice of the fused projection is needed on the paged path (:572-621)
             wq = c.get(self.qkv_proj.weight, dt)[:q_dim]
@@ -206,7 +212,8 @@ class FlashSelfAttention(_AttentionBase):
             q2d = ops.gemm_bias_act(x, wq, None if bq is None else bq[:q_dim].contiguous())
             out = self._paged(q2d, B, S, dt, kwargs, "FlashSelfAttention", r)
             return out if in_dtype == dt else out.to(in_dtype)
-        qkv = linear(x, self.qkv_proj, c, dt)  # [B,S,q_dim+2*kv_dim]; q/k/v are strided views of it
+        # [B,S,q_dim+2*kv_dim]; q/k/v are strided views of it
+        qkv = linear(x, self.qkv_proj, c, dt) if pre_norm is None else prenorm_linear(x, pre_norm, self.qkv_proj, c, dt)
         q = qkv[:, :, :q_dim].view(B, S, self.num_attention_heads, self.head_dim)
         k = qkv[:, :, q_dim:q_dim + kv_dim].view(B, S, self.num_kv_heads, self.head_dim)
         v = qkv[:, :, q_dim + kv_dim:].view(B, S, self.num_kv_heads, self.head_dim)

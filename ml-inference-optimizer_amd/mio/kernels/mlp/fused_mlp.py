@@ -58,7 +58,10 @@ class FusedMLP(nn.Module):
     def _gate(self, dtype):
         return None, None
 
-    def forward(self, hidden_states: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                pre_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
+        """pre_norm (not in the reference): a LayerNorm to apply to hidden_states first -- the pre-LN block's
+        `mlp(ln(x))` in one call, which lets LayerNorm hand its output to fc1 in the blocked layout."""
         if hidden_states.dim() != 3:
             raise ValueError(f"Expected 3D input tensor, got shape: {hidden_states.shape}")
         if not hidden_states.is_cuda:
@@ -76,8 +79,17 @@ class FusedMLP(nn.Module):
         b1 = b2 = None  # blocked weight copies, when this shape runs the kernels that take them
         if gw is None and ops.fused_mlp_blocked_weight_ok(M, d, I, act):
             b1, b2 = c.get_blocked(self.fc1.weight, dt), c.get_blocked(self.fc2.weight, dt)
+        xshape = None
+        if pre_norm is not None:
+            lw, lb = c.get(pre_norm.weight, dt), c.get(pre_norm.bias, dt)
+            if b1 is not None and d % 32 == 0 and not ops.NO_BLOCKED_X:
+                xshape = tuple(x.shape)
+                x = ops.layernorm(x, lw, lb, pre_norm.eps, out_blocked=True)
+            else:
+                x = ops.layernorm(x, lw, lb, pre_norm.eps)
         out = ops.fused_mlp(x, c.get(self.fc1.weight, dt), c.get(self.fc1.bias, dt), c.get(self.fc2.weight, dt),
-                            c.get(self.fc2.bias, dt), act, gw, gb, residual=r, fc1_blocked=b1, fc2_blocked=b2)
+                            c.get(self.fc2.bias, dt), act, gw, gb, residual=r, fc1_blocked=b1, fc2_blocked=b2,
+                            x_blocked_shape=xshape)
         return out if out.dtype == in_dtype else out.to(in_dtype)
 
 
@@ -133,7 +145,10 @@ class FusedTransformerMLP(nn.Module):
         else:
             self.mlp = FusedMLP(hidden_size, intermediate_size, self.config)
 
-    def forward(self, hidden_states: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                pre_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
+        if pre_norm is not None:
+            return self.mlp(hidden_states, residual, pre_norm)
         return self.mlp(hidden_states, residual) if residual is not None else self.mlp(hidden_states)
 
     def load_from_standard_mlp(self, state_dict: Dict[str, torch.Tensor], prefix: str = "") -> None:

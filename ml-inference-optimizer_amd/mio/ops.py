@@ -250,6 +250,7 @@ def attn_merge(o_a, lse_a, o_b, lse_b, out: Optional[torch.Tensor] = None):
 # GEMM / FusedMLP / LayerNorm
 # ------------------------------------------------------------------------------------------------
 _NO_BLOCKED_W = os.environ.get("MIO_NO_BLOCKED_W", "0") == "1"
+NO_BLOCKED_X = os.environ.get("MIO_NO_BLOCKED_X", "0") == "1"  # A/B runs: LayerNorm keeps writing the plain layout
 
 
 def block_weight(w: torch.Tensor) -> torch.Tensor:
@@ -278,7 +279,7 @@ def fused_mlp_blocked_weight_ok(M: int, d: int, I: int, activation: str) -> bool
 
 
 def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_gate=None, residual=None, out=None,
-                  w_blocked=None):
+                  w_blocked=None, x_blocked_shape=None):
     """y = act(x @ w^T + bias) (+ residual); x [..., K], w [N, K].  F.linear with a fused epilogue."""
     _need_cuda(x, w)
     if activation not in _ACT:
@@ -291,6 +292,18 @@ def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_g
     N = w.shape[0]
     if w.shape[1] != K:
         raise ValueError(f"weight shape {tuple(w.shape)} does not match input features {K}")
+    if x_blocked_shape is not None:
+        # x is layernorm(..., out_blocked=True) of a tensor of shape x_blocked_shape: blocked activation layout
+        M = int(math.prod(x_blocked_shape[:-1]))
+        if w_blocked is None or act == _lib.ACT_SWIGLU or not lib.mio_gemm_blocked_weight_ok(M, N, K, act):
+            raise ValueError("a blocked activation operand needs a blocked weight and a shape with blocked_weight_ok()")
+        if out is None:
+            out = torch.empty(*x_blocked_shape[:-1], N, dtype=x.dtype, device=x.device)
+        y2 = out.view(-1, N)
+        r2 = None if residual is None else _rows16(residual.reshape(-1, N))
+        check(lib.mio_gemm_bias_act_bw(x.data_ptr(), w_blocked.data_ptr(), _ptr(bias), _ptr(r2), y2.data_ptr(), M, N, K,
+                                       K, y2.stride(0), 0 if r2 is None else r2.stride(0), act, dt, 1, _stream()))
+        return out
     x2 = x.reshape(-1, K)
     x2, w = _rows16(x2), _rows16(w)
     M = x2.shape[0]
@@ -312,7 +325,7 @@ def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_g
     if w_blocked is not None and act != _lib.ACT_SWIGLU and lib.mio_gemm_blocked_weight_ok(M, N, K, act) and \
             x2.stride(0) * 512 < 0x7fffffff:
         check(lib.mio_gemm_bias_act_bw(x2.data_ptr(), w_blocked.data_ptr(), _ptr(bias), _ptr(r2), y2.data_ptr(), M, N, K,
-                                       x2.stride(0), y2.stride(0), 0 if r2 is None else r2.stride(0), act, dt, _stream()))
+                                       x2.stride(0), y2.stride(0), 0 if r2 is None else r2.stride(0), act, dt, 0, _stream()))
         return out
     check(lib.mio_gemm_bias_act(x2.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(w_gate), _ptr(bias_gate), _ptr(r2),
                                 y2.data_ptr(), M, N, K, x2.stride(0), w.stride(0), y2.stride(0),
@@ -332,15 +345,31 @@ def fused_mlp(
     residual: Optional[torch.Tensor] = None,
     fc1_blocked: Optional[torch.Tensor] = None,
     fc2_blocked: Optional[torch.Tensor] = None,
+    x_blocked_shape=None,
 ) -> torch.Tensor:
     """Drop-in for triton_fused_mlp (mlp_kernels.py:648-756): fc2(act(fc1(x))), hidden [B,S,d].
     "gelu" is the tanh form like the Triton kernel (:144-161); "gelu_erf" is pytorch_fused_mlp's (:782-783)."""
-    if hidden_states.dim() != 3:
+    if x_blocked_shape is None and hidden_states.dim() != 3:
         raise ValueError(f"Expected 3D input tensor, got shape: {hidden_states.shape}")
     _need_cuda(hidden_states)
     if activation not in _ACT or _ACT[activation] == _lib.ACT_NONE:
         raise ValueError(f"Unsupported activation function: {activation}")
     act = _ACT[activation]
+    if x_blocked_shape is not None:
+        # hidden_states is layernorm(..., out_blocked=True) of a [B,S,d] tensor: blocked activation layout
+        d, I = x_blocked_shape[-1], fc1_weight.shape[0]
+        M = int(math.prod(x_blocked_shape[:-1]))
+        if fc1_blocked is None or fc2_blocked is None or not lib.mio_fused_mlp_blocked_weight_ok(M, d, I, act):
+            raise ValueError("a blocked activation operand needs blocked weights and fused_mlp_blocked_weight_ok()")
+        out = torch.empty(*x_blocked_shape, dtype=hidden_states.dtype, device=hidden_states.device)
+        work = torch.empty((M + 255) // 256 * 256, I, dtype=hidden_states.dtype, device=hidden_states.device)
+        r2 = None if residual is None else residual.reshape(-1, d)
+        if r2 is not None and not r2.is_contiguous():
+            r2 = r2.contiguous()
+        check(lib.mio_fused_mlp_fwd_bw(hidden_states.data_ptr(), fc1_blocked.data_ptr(), _ptr(fc1_bias),
+                                       fc2_blocked.data_ptr(), _ptr(fc2_bias), _ptr(r2), out.data_ptr(), work.data_ptr(),
+                                       M, d, I, act, _dtype_id(hidden_states), 1, _stream()))
+        return out
     if act == _lib.ACT_SWIGLU and fc1_gate_weight is None:
         raise ValueError("SwiGLU activation requires gate weights")
     dt = _dtype_id(hidden_states)
@@ -369,7 +398,7 @@ def fused_mlp(
     if fc1_blocked is not None and fc2_blocked is not None and lib.mio_fused_mlp_blocked_weight_ok(M, d, I, act):
         check(lib.mio_fused_mlp_fwd_bw(x2.data_ptr(), fc1_blocked.data_ptr(), _ptr(fc1_bias), fc2_blocked.data_ptr(),
                                        _ptr(fc2_bias), _ptr(r2), out.data_ptr(), work.data_ptr(), M, d, I, act, dt,
-                                       _stream()))
+                                       0, _stream()))
         return out
     check(lib.mio_fused_mlp_fwd(x2.data_ptr(), fc1_weight.data_ptr(), _ptr(fc1_bias), _ptr(gate_w), _ptr(gate_b),
                                 fc2_weight.data_ptr(), _ptr(fc2_bias), _ptr(r2), out.data_ptr(), work.data_ptr(),
@@ -378,8 +407,10 @@ def fused_mlp(
 
 
 def layernorm(x, weight, bias=None, eps: float = 1e-5, residual=None, residual_alpha: float = 1.0,
-              return_sum: bool = False):
-    """Drop-in for triton_layernorm (layernorm_kernels.py:191-276): optional x + alpha*residual first."""
+              return_sum: bool = False, out_blocked: bool = False):
+    """Drop-in for triton_layernorm (layernorm_kernels.py:191-276): optional x + alpha*residual first.
+    out_blocked: y is returned as a [ceil(rows/256)*256, cols] tensor in the blocked activation layout
+    (include/mio_hip.h) for a following gemm_bias_act / fused_mlp with x_blocked_shape=x.shape."""
     _need_cuda(x, weight)
     dt = _dtype_id(x)
     cols = x.shape[-1]
@@ -391,11 +422,18 @@ def layernorm(x, weight, bias=None, eps: float = 1e-5, residual=None, residual_a
         r2 = residual.reshape(-1, cols)
         if not r2.is_contiguous():
             r2 = r2.contiguous()
-    y = torch.empty_like(x2)
     s = torch.empty_like(x2) if (return_sum and r2 is not None) else None
-    check(lib.mio_layernorm_fwd(x2.data_ptr(), _ptr(r2), weight.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(s),
-                                x2.shape[0], cols, float(eps), float(residual_alpha), dt, _stream()))
-    y = y.view(x.shape)
+    if out_blocked:
+        if cols % 32 != 0:
+            raise ValueError("out_blocked needs cols % 32 == 0")
+        y = torch.empty((x2.shape[0] + 255) // 256 * 256, cols, dtype=x.dtype, device=x.device)
+        check(lib.mio_layernorm_fwd_bx(x2.data_ptr(), _ptr(r2), weight.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(s),
+                                       x2.shape[0], cols, float(eps), float(residual_alpha), dt, _stream()))
+    else:
+        y = torch.empty_like(x2)
+        check(lib.mio_layernorm_fwd(x2.data_ptr(), _ptr(r2), weight.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(s),
+                                    x2.shape[0], cols, float(eps), float(residual_alpha), dt, _stream()))
+        y = y.view(x.shape)
     if return_sum:
         return y, (s.view(x.shape) if s is not None else x)
     return y

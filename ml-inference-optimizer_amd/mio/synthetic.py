@@ -35,8 +35,10 @@ class Block(nn.Module):
         self.mlp = FusedTransformerMLP(d, I, activation, FusedMLPConfig(precision=precision))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.attn(self.ln_1(x), residual=x)
-        return self.mlp(self.ln_2(x), residual=x)
+        # pre_norm=: the module applies the LayerNorm itself (same kernels; at large sizes LayerNorm then writes its
+        # output in the blocked layout the following GEMM fetches contiguously)
+        x = self.attn(x, residual=x, pre_norm=self.ln_1)
+        return self.mlp(x, residual=x, pre_norm=self.ln_2)
 
 
 class GPT2ShapedStack(nn.Module):

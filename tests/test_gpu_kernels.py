@@ -365,6 +365,46 @@ def test_gemm_big_tiles_exact():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_layernorm_blocked_handover(dtype):
+    """LayerNorm -> GEMM hand-over in the blocked activation layout: layout exactness of mio_layernorm_fwd_bx against
+    the definition, then the blocked-x GEMM and fused MLP against the plain-layout launches of the same kernels (same
+    arithmetic -> same bits).  Ragged M exercises the partly filled last 256-row block."""
+    ops = _ops()
+    torch.manual_seed(21)
+    M, d, I = 16384 + 100, 1024, 1024
+    x = torch.randn(1, M, d, device=DEV).to(dtype)
+    g = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype)
+    be = (0.1 * torch.randn(d, device=DEV)).to(dtype)
+    y = ops.layernorm(x, g, be)
+    yb = ops.layernorm(x, g, be, out_blocked=True)
+    Mp = (M + 255) // 256 * 256
+    assert tuple(yb.shape) == (Mp, d)
+    want = torch.zeros(Mp, d, dtype=dtype, device=DEV)
+    want[:M] = y[0]
+    want = want.view(Mp // 256, 256, d // 32, 32).permute(0, 2, 1, 3).reshape(Mp, d)
+    got = yb.clone()
+    got.view(Mp // 256, d // 32, 256, 32)[-1, :, M % 256:, :] = 0  # rows past M are never written
+    assert torch.equal(got, want)
+    w = (torch.randn(I, d, device=DEV) * 0.03).to(dtype)
+    b = (torch.randn(I, device=DEV) * 0.1).to(dtype)
+    r = torch.randn(1, M, I, device=DEV).to(dtype)
+    wb = ops.block_weight(w)
+    z_plain = ops.gemm_bias_act(y, w, b, "none", residual=r, w_blocked=wb)
+    z_blk = ops.gemm_bias_act(yb, w, b, "none", residual=r, w_blocked=wb, x_blocked_shape=tuple(x.shape))
+    assert torch.equal(z_blk, z_plain)
+    z_plain = ops.gemm_bias_act(y, w, b, "gelu", w_blocked=wb)                      # persistent kernel
+    z_blk = ops.gemm_bias_act(yb, w, b, "gelu", w_blocked=wb, x_blocked_shape=tuple(x.shape))
+    assert torch.equal(z_blk, z_plain)
+    w2 = (torch.randn(d, I, device=DEV) * 0.03).to(dtype)
+    b2 = (torch.randn(d, device=DEV) * 0.1).to(dtype)
+    w2b = ops.block_weight(w2)
+    m_plain = ops.fused_mlp(y, w, b, w2, b2, "gelu", residual=x, fc1_blocked=wb, fc2_blocked=w2b)
+    m_blk = ops.fused_mlp(yb, w, b, w2, b2, "gelu", residual=x, fc1_blocked=wb, fc2_blocked=w2b,
+                          x_blocked_shape=tuple(x.shape))
+    assert torch.equal(m_blk, m_plain)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_layernorm(golden_dir, dtype):
     ops = _ops()
     g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "layernorm.npz")).items()}

@@ -275,3 +275,22 @@ def test_composed_functional_entry_points():
     q3, k3, v3 = ops.ring_compatible_wrapper(*dev(x, g, b, *ws, *bs), num_heads=H)
     assert tuple(q3.shape) == (B, H, S, d // H) and torch.equal(q3.permute(0, 2, 1, 3), q)
     assert ops._infer_heads(1280, 0) == 20 and ops._infer_heads(1024, 0) == 16 and ops._infer_heads(96, 0) == 1
+
+
+def test_block_prenorm_equals_decomposed():
+    """synthetic.Block at a size where LayerNorm hands over in the blocked layout (pre_norm=) == the same block with
+    the LayerNorms applied outside the modules (plain layout): same kernels, same arithmetic -> same bits."""
+    from mio.synthetic import Block
+    torch.manual_seed(8)
+    d, H, I, B, S = 1024, 16, 1024, 4, 4096 + 25
+    blk = Block(d, H, I, causal=True, precision="bf16").to(DEV, torch.bfloat16).eval()
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.03)
+        blk.ln_1.weight.add_(1.0)
+        blk.ln_2.weight.add_(1.0)
+        x = torch.randn(B, S, d, device=DEV, dtype=torch.bfloat16)
+        y = blk(x)
+        a = blk.attn(blk.ln_1(x), residual=x)
+        ref = blk.mlp(blk.ln_2(a), residual=a)
+    assert torch.equal(y, ref)
