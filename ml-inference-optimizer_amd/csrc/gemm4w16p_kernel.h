@@ -21,8 +21,8 @@
 //     the next wait (8 micro-steps later) they have normally been acknowledged and the wait does not see them.
 //   * the load stream never drains between tiles: the last three K-tiles of a tile prefetch K-tiles 0..2 of the
 //     workgroup's NEXT tile (the LDS stage index runs on across tiles), so the only per-tile bubble left is the
-//     ~4k-cycle accumulator read-out, during which those loads land.  The bias row of the tile is fetched before
-//     those three K-tiles.
+//     ~4k-cycle accumulator read-out, during which those loads land.  The bias row of the tile is fetched (into
+//     LDS) before those three K-tiles.
 // Everything else (tile shape, LDS stages and swizzle, buffer_load-to-LDS prefetch, asm-owned accumulators,
 // micro-step order) is gemm4w16_kernel's.  Requires K % 64 == 0 (an even number of K-tiles keeps the fragment
 // double-buffer parity across tiles) and SPK * (K / 32) >= 32; no residual operand.
@@ -33,6 +33,9 @@
 
 typedef __attribute__((ext_vector_type(32))) uint32_t u32x32_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+constexpr int G6P_BIAS_OFF = G6_SMEM;          // 4 waves x 256 B: each wave's slice of the tile's bias row
+constexpr int G6P_SMEM = G6_SMEM + 4 * 256;
 
 template <typename T, int ACT, int SPK, bool STAMP = false>
 __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
@@ -47,7 +50,6 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
   const int c16 = lane & 15, g = lane >> 4;
   const int nk = p.K / G6_BK;
   const int ntiles = p.tiles_m * p.tiles_n;
-  const int prow = lane >> 2, pcs = lane & 3;
 
   // fragment read offsets (tile independent)
   const int co = (g ^ g6_swz(c16)) * 16;
@@ -81,6 +83,14 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
   int64_t m0 = 0;
   int n0 = 0, nrem = 0;
   int64_t mrem = 0;
+  // lane id recomputed from an opaque instruction wherever lane-constant addresses are built inside the tile loop:
+  // hoisted to kernel entry they are spilled around the loop, and the reload's compiler-inserted vmcnt(0) drains the
+  // hand-placed prefetch (cdna_hip_programming.md, attention pitfalls)
+  auto lane_now = [&]() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
   auto setup = [&](int tile) {
     int tm, tn;
     gemm_tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
@@ -88,6 +98,7 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
     n0 = tn * 256;
     mrem = p.M - m0;
     nrem = p.N - n0;
+    const int ln = lane_now(), prow = ln >> 2, pcs = ln & 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (wave * 4 + i) * 16 + prow;
@@ -253,16 +264,19 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
     const int64_t om0 = m0;
     const int on0 = n0, onrem = nrem;
     const int omrem = mrem < 256 ? (int)mrem : 256;
-    u32x2_t bq[8];
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt) bq[nt] = (u32x2_t){0u, 0u};
+    // bias: each wave DMAs the 256 B slice of the bias row under its own 128 columns into its private LDS slot (one
+    // global_load_lds_dword: 64 lanes x 4 B) and reads it back in the read-out.  Held in registers from here the 16
+    // values do not fit beside the output buffers and fragments: hipcc spills them with a vmcnt(0) in front of the
+    // tail K-tiles.  The request is older than the 24 loads the tail issues, so the counted waits there cover it.
     if (p.bias != nullptr) {
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-        const int n = on0 + wc * 128 + nt * 16 + 4 * g;
-        const int nc = (n < p.N) ? n : (p.N - 4);
-        bq[nt] = *(const u32x2_t*)((const T*)p.bias + nc);
-      }
+      const int ln = lane_now();
+      const int n = on0 + wc * 128 + 2 * ln;
+      const int nc = n < p.N - 2 ? n : p.N - 2;  // columns past N are never stored
+      const uint32_t lds = (uint32_t)(size_t)((MIO_LDS char*)(smem + G6P_BIAS_OFF + wave * 256));
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                   :
+                   : "s"(lds), "v"(nc * 2), "s"(p.bias)
+                   : "memory", "m0");
     }
     const int next = tile + (int)gridDim.x;
     const bool has_next = next < ntiles;
@@ -278,6 +292,14 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
     // (the last MFMAs must have retired before the accumulator file is read: no interlock for asm readers)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     {
+      u32x2_t bq[8];
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) bq[nt] = (u32x2_t){0u, 0u};
+      if (p.bias != nullptr) {
+        const char* bl = smem + G6P_BIAS_OFF + wave * 256 + 8 * (lane_now() >> 4);
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) bq[nt] = *(const u32x2_t*)(bl + nt * 32);
+      }
       auto pair = [&](auto MTP) {
         constexpr int mtp = decltype(MTP)::value, mt = 2 * mtp;
         auto col = [&](auto NT) {
@@ -308,10 +330,12 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
       }
     }
     // where this tile's chunks go
-    yrs_prev = __builtin_amdgcn_make_buffer_rsrc(
-        p.y_blk ? (void*)((char*)p.y + (((om0 >> 8) * (int64_t)(p.N >> 5) + (on0 >> 5)) << 14))
-                : (void*)((T*)p.y + om0 * p.ldy + on0),
-        0, 0x7fffffff, 0x00020000);
+    {  // (wave-uniform 64-bit offset, forced into scalar registers: as vector values hipcc computes it before the tail
+       //  K-tiles and spills it around them)
+      const int64_t yb = p.y_blk ? (((om0 >> 8) * (int64_t)(p.N >> 5) + (on0 >> 5)) << 14) : (om0 * p.ldy + on0) * 2;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)yb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(yb >> 32));
+      yrs_prev = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.y + (((uint64_t)hi << 32) | lo)), 0, 0x7fffffff, 0x00020000);
+    }
     nchunks_prev = 32;
     full_prev = (omrem == 256) && (onrem >= 256);
     mrem_prev = omrem;

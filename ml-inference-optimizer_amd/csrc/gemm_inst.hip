@@ -144,7 +144,7 @@ static int launch_4w16p(GemmDev p, hipStream_t stream) {
   static bool attr_set = false;
   static int ncu = 256;
   if (!attr_set || p.dbg != nullptr) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G6_SMEM);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G6P_SMEM);
     if (e != hipSuccess) return mio_fail(std::string("gemm4w16p: hipFuncSetAttribute: ") + hipGetErrorString(e));
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) == hipSuccess &&
@@ -153,7 +153,7 @@ static int launch_4w16p(GemmDev p, hipStream_t stream) {
     attr_set = true;
   }
   const int tiles = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL(kern, dim3(tiles < ncu ? tiles : ncu), dim3(256), G6_SMEM, stream, p);
+  hipLaunchKernelGGL(kern, dim3(tiles < ncu ? tiles : ncu), dim3(256), G6P_SMEM, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mio_fail(std::string("gemm4w16p launch: ") + hipGetErrorString(e));
   return 0;
