@@ -6,6 +6,8 @@
 // :1206-1311) and _reshape_and_cache_kernel (:811-905, wrapper :1314-1407).
 // Cache layout [num_blocks, num_layers, block_size, Hkv, D]; token t of sequence b lives in physical
 // block block_tables[b, t / block_size] at slot t % block_size (:728-751).
+#include <cstdlib>
+
 #include "mio_common.h"
 
 struct DecDev {
@@ -24,7 +26,12 @@ struct DecDev {
 
 static inline int dec_nsplit(int B, int H, int q_len, int max_ctx) {
   const int64_t rows = (int64_t)B * H * q_len;
-  int want = (int)((1024 + rows - 1) / rows);
+  static const int wgs = [] {  // MIO_DEC_WGS: workgroups the split aims for (tuning aid; default 512 = 2 per CU)
+    const char* e = std::getenv("MIO_DEC_WGS");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : 512;
+  }();
+  int want = (int)((wgs + rows - 1) / rows);
   int cap = (max_ctx + 255) / 256;
   if (cap < 1) cap = 1;
   if (want > cap) want = cap;
@@ -33,7 +40,7 @@ static inline int dec_nsplit(int B, int H, int q_len, int max_ctx) {
 }
 
 // CPRP = chunks-per-row padded to a power of two (8 for D <= 64, 16 for D <= 128)
-template <typename T, int CPRP>
+template <typename T, int CPRP, int U>
 __global__ __launch_bounds__(256) void decode_paged_kernel(const DecDev p) {
   constexpr int TPI = 64 / CPRP;  // tokens per wave-iteration
   constexpr int NSTATE = 4 * TPI;
@@ -69,33 +76,95 @@ __global__ __launch_bounds__(256) void decode_paged_kernel(const DecDev p) {
 
   const int64_t tok_stride = (int64_t)p.Hkv * p.D;
   const int64_t blk_stride = (int64_t)p.L * p.bs * tok_stride;
-  const int64_t lay_off = (int64_t)p.layer * p.bs * tok_stride + (int64_t)kvh * p.D + 8 * c;
 
-  for (int pos0 = begin + wave * TPI; pos0 < end; pos0 += 4 * TPI) {
-    const int pos = pos0 + t;
-    const bool ok = (pos < end) && c_ok && (pos / p.bs < p.max_blocks);
-    u32x4_t kr = {0, 0, 0, 0}, vr = {0, 0, 0, 0};
-    if (ok) {
-      const int pb = p.bt[(int64_t)b * p.max_blocks + pos / p.bs];
-      const int64_t off = (int64_t)pb * blk_stride + lay_off + (int64_t)(pos % p.bs) * tok_stride;
-      kr = *(const u32x4_t*)((const T*)p.kc + off);
-      vr = *(const u32x4_t*)((const T*)p.vc + off);
+  // U wave-iterations (U * TPI tokens per wave) per batch, two batches in flight: the K/V rows of batch i+1 and the
+  // block-table entries of batch i+2 are requested before batch i is reduced, and one max / rescale serves the U
+  // tokens of a batch.  Measured (tools/dbg/dec_sweep.sh): U = 1 .. 4 are within 2 % of each other, U = 8 is 3-5 %
+  // slower -- the kernel is bound by the 128-byte-pieces-at-token-stride access pattern (5.2-5.4 TB/s at B 64), not
+  // by loads in flight.
+  constexpr int STEP = 4 * TPI;  // tokens the workgroup's four waves cover per iteration
+  // Loads are unconditional (addresses clamped to the split's last token / the row's first chunk, values masked in
+  // `reduce`): predicated loads become branches, and hipcc drains vmcnt at every join, which serialises the batches.
+  const int last = end - 1;  // >= begin here: empty splits skip the loop
+  const int coff = c_ok ? 8 * c : 0;
+  const int64_t lay_off = (int64_t)p.layer * p.bs * tok_stride + (int64_t)kvh * p.D + coff;
+  const int32_t* btrow = p.bt + (int64_t)b * p.max_blocks;
+  auto load_pb = [&](int pos0, int (&pb)[U]) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int pos = min(pos0 + j * STEP + t, last);
+      pb[j] = btrow[min(pos / p.bs, p.max_blocks - 1)];
     }
-    const typename DT<T>::x8 kv = __builtin_bit_cast(typename DT<T>::x8, kr);
-    const typename DT<T>::x8 vv = __builtin_bit_cast(typename DT<T>::x8, vr);
-    float s = 0.f;
+  };
+  auto load_kv = [&](int pos0, const int (&pb)[U], u32x4_t (&kr)[U], u32x4_t (&vr)[U]) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += qf[i] * (float)kv[i];
+    for (int j = 0; j < U; ++j) {
+      const int pos = min(pos0 + j * STEP + t, last);
+      const int64_t off = (int64_t)pb[j] * blk_stride + lay_off + (int64_t)(pos % p.bs) * tok_stride;
+      kr[j] = *(const u32x4_t*)((const T*)p.kc + off);
+      vr[j] = *(const u32x4_t*)((const T*)p.vc + off);
+    }
+  };
+  auto reduce = [&](int pos0, const int (&pb)[U], const u32x4_t (&kr)[U], const u32x4_t (&vr)[U]) {
+    float sc[U];
+    float m_new = m;
 #pragma unroll
-    for (int x = 1; x < CPRP; x <<= 1) s += __shfl_xor(s, x, 64);
-    if (pos < end) {  // uniform within the token's lane group
-      const float m_new = fmaxf(m, s);
-      const float alpha = __expf(m - m_new);
-      const float pe = __expf(s - m_new);
-      l = l * alpha + pe;
+    for (int j = 0; j < U; ++j) {
+      const typename DT<T>::x8 kv = __builtin_bit_cast(typename DT<T>::x8, kr[j]);
+      float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = o[i] * alpha + pe * (float)vv[i];
-      m = m_new;
+      for (int i = 0; i < 8; ++i) s += qf[i] * (float)kv[i];  // qf = 0 in the padding chunks (c_ok false)
+#pragma unroll
+      for (int x = 1; x < CPRP; x <<= 1) s += __shfl_xor(s, x, 64);
+      const int pos = pos0 + j * STEP + t;
+      sc[j] = (pos < end && pos / p.bs < p.max_blocks) ? s : -INFINITY;  // uniform within the token's lane group
+      m_new = fmaxf(m_new, sc[j]);
+    }
+    const float m_ref = (m_new == -INFINITY) ? 0.f : m_new;  // nothing seen yet: every weight below is exp(-inf) = 0
+    const float alpha = __expf(m - m_ref);
+    l *= alpha;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] *= alpha;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const typename DT<T>::x8 vv = __builtin_bit_cast(typename DT<T>::x8, vr[j]);
+      const float pe = __expf(sc[j] - m_ref);
+      l += pe;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] += pe * (float)vv[i];
+    }
+    m = m_new;
+  };
+  {
+    constexpr int BATCH = U * STEP;
+    int pbA[U], pbB[U], pbC[U];  // block ids of the batch being reduced, the next one, and the one after
+    u32x4_t kA[U], vA[U], kB[U], vB[U];
+    auto shift = [&]() {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        pbA[j] = pbB[j];
+        pbB[j] = pbC[j];
+      }
+    };
+    int pos0 = begin + wave * TPI;
+    if (begin >= end) pos0 = end;  // empty split: no loads at all
+    else {
+    load_pb(pos0, pbA);
+    load_pb(pos0 + BATCH, pbB);
+    load_kv(pos0, pbA, kA, vA);
+    }
+    while (pos0 < end) {
+      load_pb(pos0 + 2 * BATCH, pbC);
+      load_kv(pos0 + BATCH, pbB, kB, vB);
+      reduce(pos0, pbA, kA, vA);
+      pos0 += BATCH;
+      if (pos0 >= end) break;
+      shift();
+      load_pb(pos0 + 2 * BATCH, pbC);
+      load_kv(pos0 + BATCH, pbB, kA, vA);
+      reduce(pos0, pbA, kB, vB);
+      pos0 += BATCH;
+      shift();
     }
   }
 
@@ -149,6 +218,29 @@ __global__ __launch_bounds__(128) void decode_reduce_kernel(const DecDev p) {
   ((T*)p.o)[b * p.os_b + h * p.os_h + (int64_t)qi * p.os_s + d] = (T)((W > 0.f) ? acc / W : 0.f);
 }
 
+static int dec_unroll() {  // MIO_DEC_U = 1 | 2 | 4 | 8: wave-iterations per batch (tuning aid, read per call; default 2)
+  const char* e = std::getenv("MIO_DEC_U");
+  const int u = e ? std::atoi(e) : 2;
+  return (u == 1 || u == 4 || u == 8) ? u : 2;
+}
+
+template <typename T, int CPRP>
+static void dec_launch_u(const DecDev& p, dim3 grid, hipStream_t st) {
+  switch (dec_unroll()) {
+    case 1: hipLaunchKernelGGL((decode_paged_kernel<T, CPRP, 1>), grid, dim3(256), 0, st, p); break;
+    case 4: hipLaunchKernelGGL((decode_paged_kernel<T, CPRP, 4>), grid, dim3(256), 0, st, p); break;
+    case 8: hipLaunchKernelGGL((decode_paged_kernel<T, CPRP, 8>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((decode_paged_kernel<T, CPRP, 2>), grid, dim3(256), 0, st, p); break;
+  }
+}
+
+template <typename T>
+static void dec_launch(const DecDev& p, dim3 grid, hipStream_t st) {
+  if (p.D <= 64) dec_launch_u<T, 8>(p, grid, st);
+  else dec_launch_u<T, 16>(p, grid, st);
+  if (p.nsplit > 1) hipLaunchKernelGGL(decode_reduce_kernel<T>, dim3(grid.x), dim3(128), 0, st, p);
+}
+
 extern "C" size_t mio_fa3_decode_workspace_bytes(int32_t B, int32_t H, int32_t q_len, int32_t D, int32_t max_ctx) {
   const int ns = dec_nsplit(B, H, q_len, max_ctx);
   return (size_t)B * H * q_len * ns * (size_t)(D + 1) * sizeof(float) + 256;
@@ -186,15 +278,8 @@ extern "C" int mio_fa3_decode_paged(const void* q, void* o, const void* k_cache,
   p.ws_lse = p.ws_o ? p.ws_o + rows * p.nsplit * D : nullptr;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)rows, (unsigned)p.nsplit), block(256);
-  if (dtype == MIO_BF16) {
-    if (D <= 64) hipLaunchKernelGGL((decode_paged_kernel<__bf16, 8>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((decode_paged_kernel<__bf16, 16>), grid, block, 0, st, p);
-    if (p.nsplit > 1) hipLaunchKernelGGL(decode_reduce_kernel<__bf16>, dim3((unsigned)rows), dim3(128), 0, st, p);
-  } else {
-    if (D <= 64) hipLaunchKernelGGL((decode_paged_kernel<_Float16, 8>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((decode_paged_kernel<_Float16, 16>), grid, block, 0, st, p);
-    if (p.nsplit > 1) hipLaunchKernelGGL(decode_reduce_kernel<_Float16>, dim3((unsigned)rows), dim3(128), 0, st, p);
-  }
+  if (dtype == MIO_BF16) dec_launch<__bf16>(p, grid, st);
+  else dec_launch<_Float16>(p, grid, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mio_fail(std::string("decode_paged launch: ") + hipGetErrorString(e));
   return 0;

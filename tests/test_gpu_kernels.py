@@ -449,6 +449,29 @@ def test_paged_decode_and_cache(dtype, D, H, Hkv, q_len):
     _cmp(out, oracle.paged_attention_forward(q, kc, vc, bt, ctx2, bs, 1), dtype, "paged+1")
 
 
+@pytest.mark.parametrize("unroll", ["1", "2", "4", "8"])
+def test_paged_decode_pipelined_batches(unroll, monkeypatch):
+    """Ragged contexts long enough for several double-buffered batches and the split + reduce path, at every
+    unroll factor the launcher can pick (MIO_DEC_U is read per call); contexts that end inside a batch, inside a
+    block, at a split boundary, and one empty sequence."""
+    ops = _ops()
+    monkeypatch.setenv("MIO_DEC_U", unroll)
+    torch.manual_seed(7)
+    dtype = torch.bfloat16
+    for D, H, Hkv in ((64, 4, 4), (128, 4, 2)):
+        B, bs, L, maxb = 6, 16, 1, 80
+        nblk = B * maxb
+        ctx = torch.tensor([1280, 1023, 513, 257, 1, 0], dtype=torch.int32)
+        kc = torch.randn(nblk, L, bs, Hkv, D).to(dtype)
+        vc = torch.randn(nblk, L, bs, Hkv, D).to(dtype)
+        bt = torch.randperm(nblk).view(B, maxb).to(torch.int32)
+        q = torch.randn(B, H, 1, D).to(dtype)
+        out = torch.empty(B, H, 1, D, dtype=dtype, device=DEV)
+        ops.paged_attention_forward(q.to(DEV), out, kc.to(DEV), vc.to(DEV), bt.to(DEV), ctx.to(DEV), bs, 1280, 0)
+        _cmp(out, oracle.paged_attention_forward(q, kc, vc, bt, ctx, bs, 0), dtype, f"paged U={unroll} D={D}")
+        assert out[5].abs().max() == 0
+
+
 def test_errors_raise_before_launch():
     ops = _ops()
     q = torch.randn(1, 8, 2, 64, dtype=torch.float16, device=DEV)

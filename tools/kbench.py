@@ -91,16 +91,19 @@ def main():
         t = timeit(lambda: ops.layernorm(x, w, w, residual=x, return_sum=True), a.iters)
         print(f"residual+layernorm: {t*1e6:.1f} us  {4*M*d*2/t/1e12:.2f} TB/s")
     if a.what in ("all", "decode"):
-        bs, L, ctxlen = 16, 1, 4096
-        nblk = B * ctxlen // bs
-        kc = torch.randn(nblk, L, bs, H, D, device=dev, dtype=dt)
-        vc = torch.randn(nblk, L, bs, H, D, device=dev, dtype=dt)
-        bt = torch.randperm(nblk, device=dev).view(B, -1).to(torch.int32)
-        cl = torch.full((B,), ctxlen, device=dev, dtype=torch.int32)
-        q = torch.randn(B, H, 1, D, device=dev, dtype=dt)
-        o = torch.empty_like(q)
-        t = timeit(lambda: ops.paged_attention_forward(q, o, kc, vc, bt, cl, bs, ctxlen, 0), a.iters)
-        print(f"paged decode ctx=4096: {t*1e6:.1f} us  {2*B*ctxlen*d*2/t/1e12:.2f} TB/s")
+        # B 8: K + V = 128 MiB, resident in the 256 MiB Infinity Cache across timed repeats; B 64: 1 GiB, streams from HBM
+        for Bd, Hd, Dd in ((8, H, D), (64, H, D), (32, 8, 128)):
+            bs, L, ctxlen = 16, 1, 4096
+            nblk = Bd * ctxlen // bs
+            kc = torch.randn(nblk, L, bs, Hd, Dd, device=dev, dtype=dt)
+            vc = torch.randn(nblk, L, bs, Hd, Dd, device=dev, dtype=dt)
+            bt = torch.randperm(nblk, device=dev).view(Bd, -1).to(torch.int32)
+            cl = torch.full((Bd,), ctxlen, device=dev, dtype=torch.int32)
+            q = torch.randn(Bd, Hd, 1, Dd, device=dev, dtype=dt)
+            o = torch.empty_like(q)
+            t = timeit(lambda: ops.paged_attention_forward(q, o, kc, vc, bt, cl, bs, ctxlen, 0), a.iters)
+            print(f"paged decode B={Bd} H={Hd} D={Dd} ctx=4096: {t*1e6:.1f} us  {2*Bd*ctxlen*Hd*Dd*2/t/1e12:.2f} TB/s")
+            del kc, vc
 
 
 if __name__ == "__main__":
