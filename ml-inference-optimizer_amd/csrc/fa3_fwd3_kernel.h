@@ -266,7 +266,11 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
   // Causal: this workgroup handles query block nqblk-1-qi (heavy) and then block qi (light): equal work for every
   // workgroup.  Non-causal: one block.
   const int npass = (CAUSAL && (p.nqblk - 1 - qi) != qi) ? 2 : 1;
+  unsigned long long st_all[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // diagnostic build: sums over both passes
+  if constexpr (STAMP) st_all[7] = __builtin_amdgcn_s_memtime();
   for (int pass = 0; pass < npass; ++pass) {
+    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, pt4 = 0;
+    if constexpr (STAMP) pt0 = __builtin_amdgcn_s_memtime();
     const int qblk = CAUSAL ? (pass == 0 ? p.nqblk - 1 - qi : qi) : qi;
     const int q0 = qblk * FA3_BM;
     const int wrow0 = q0 + wave * (32 * QT);  // first query row of this wave
@@ -277,17 +281,6 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       qrow[qt] = wrow0 + 32 * qt + r;
       q_ok[qt] = qrow[qt] < p.Sq;
     }
-
-    // ---- Q as MFMA B fragments in the accumulator file (lane (r,h) holds Q[row][16ks + 8h .. +7])
-    fa2_for<QT * KS>([&](auto QK_) {
-      constexpr int qt = decltype(QK_)::value / KS, ks = decltype(QK_)::value % KS;
-      const T* qp = (const T*)p.q + b * p.qs_b + head * p.qs_h + (int64_t)(q_ok[qt] ? qrow[qt] : 0) * p.qs_s;
-      const int d0 = 16 * ks + 8 * h;
-      u32x4_t raw = *(const u32x4_t*)(qp + (d0 < p.D ? d0 : 0));
-      if (!(q_ok[qt] && d0 < p.D)) raw = (u32x4_t){0, 0, 0, 0};
-      constexpr int R = FA3_A_Q + 4 * KS * qt + 4 * ks;
-      Fa3AW<R + 0>::w(raw[0]); Fa3AW<R + 1>::w(raw[1]); Fa3AW<R + 2>::w(raw[2]); Fa3AW<R + 3>::w(raw[3]);
-    });
 
     // ---- running state per query sub-tile: m_i = reference the probabilities are taken against (exp2 domain; -inf =
     // no finite score yet, the reference is then 0), negref = -reference as used by the scale-and-subtract
@@ -306,35 +299,6 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
         }
       }
     }
-    fa2_for<QT>([&](auto QTI) {
-      constexpr int qt = decltype(QTI)::value;
-      const f32x4_t lv = {lcarry[qt], lcarry[qt], lcarry[qt], lcarry[qt]};
-      Fa2AccIO<FA3_T_L + qt>::template write4<0>(lv);
-      Fa2AccIO<FA3_T_L + qt>::template write4<1>(lv);
-      Fa2AccIO<FA3_T_L + qt>::template write4<2>(lv);
-      Fa2AccIO<FA3_T_L + qt>::template write4<3>(lv);
-    });
-    fa2_for<QT * DT_>([&](auto K) {
-      constexpr int k = decltype(K)::value;
-      constexpr int qt = k / DT_, dt = k % DT_;
-      f32x4_t z[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) z[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      if (p.carry_in && q_ok[qt]) {
-        const float* oa = p.o_acc + (((int64_t)b * p.Sq + qrow[qt]) * p.H + head) * p.D;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d0 = 32 * dt + 8 * g + 4 * h;
-          if (d0 < p.D) z[g] = *(const f32x4_t*)(oa + d0);
-        }
-      }
-      Fa2AccIO<FA3_T_O + k>::template write4<0>(z[0]);
-      Fa2AccIO<FA3_T_O + k>::template write4<1>(z[1]);
-      Fa2AccIO<FA3_T_O + k>::template write4<2>(z[2]);
-      Fa2AccIO<FA3_T_O + k>::template write4<3>(z[3]);
-    });
-    asm volatile("s_nop 7" ::: "memory");  // accumulator-file writes settle before the first MFMA reads them
-
     // ---- tiles: the workgroup walks n_tiles (barriers, staging); this wave computes the first n_w of them
     int n_tiles, n_w;
     if (CAUSAL) {
@@ -432,12 +396,64 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       fa2_for<UPW>([&](auto I_) { dma_unit(I_, tile); });
     };
 
+    if constexpr (STAMP) pt1 = __builtin_amdgcn_s_memtime();
     __syncthreads();  // the previous pass is done with every LDS stage
     stage_dma(0);
     stage_dma(1);
     stage_dma(2);
+    // ---- Q rows (lane (r,h) holds Q[row][16ks + 8h .. +7]), requested right behind the first tiles: loads only, from
+    // clamped addresses, all issued before anything waits (rows past Sq and chunks past D are zeroed when the fragments
+    // are committed: a conditional next to the load becomes a branch with a vmcnt(0) in it, and an accumulator-file
+    // write per load serialises the eight latencies -- 5k cycles per pass measured, tools/fa_stamps.py)
+    u32x4_t qraw[QT * KS];
+    fa2_for<QT * KS>([&](auto QK_) {
+      constexpr int qt = decltype(QK_)::value / KS, ks = decltype(QK_)::value % KS;
+      const T* qp = (const T*)p.q + b * p.qs_b + head * p.qs_h + (int64_t)(q_ok[qt] ? qrow[qt] : 0) * p.qs_s;
+      const int d0 = 16 * ks + 8 * h;
+      qraw[qt * KS + ks] = *(const u32x4_t*)(qp + (d0 < p.D ? d0 : 0));
+    });
+    // ---- O^T and L start from zero (or the carried state): set up under the latency of those requests
+    fa2_for<QT>([&](auto QTI) {
+      constexpr int qt = decltype(QTI)::value;
+      const f32x4_t lv = {lcarry[qt], lcarry[qt], lcarry[qt], lcarry[qt]};
+      Fa2AccIO<FA3_T_L + qt>::template write4<0>(lv);
+      Fa2AccIO<FA3_T_L + qt>::template write4<1>(lv);
+      Fa2AccIO<FA3_T_L + qt>::template write4<2>(lv);
+      Fa2AccIO<FA3_T_L + qt>::template write4<3>(lv);
+    });
+    fa2_for<QT * DT_>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      constexpr int qt = k / DT_, dt = k % DT_;
+      f32x4_t z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (p.carry_in && q_ok[qt]) {
+        const float* oa = p.o_acc + (((int64_t)b * p.Sq + qrow[qt]) * p.H + head) * p.D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = 32 * dt + 8 * g + 4 * h;
+          if (d0 < p.D) z[g] = *(const f32x4_t*)(oa + d0);
+        }
+      }
+      Fa2AccIO<FA3_T_O + k>::template write4<0>(z[0]);
+      Fa2AccIO<FA3_T_O + k>::template write4<1>(z[1]);
+      Fa2AccIO<FA3_T_O + k>::template write4<2>(z[2]);
+      Fa2AccIO<FA3_T_O + k>::template write4<3>(z[3]);
+    });
+
+    // ---- Q as MFMA B fragments in the accumulator file
+    fa2_for<QT * KS>([&](auto QK_) {
+      constexpr int qt = decltype(QK_)::value / KS, ks = decltype(QK_)::value % KS;
+      constexpr int R = FA3_A_Q + 4 * KS * qt + 4 * ks;
+      u32x4_t raw = qraw[qt * KS + ks];
+      const uint32_t keep = (q_ok[qt] && 16 * ks + 8 * h < p.D) ? 0xffffffffu : 0u;
+      raw[0] &= keep; raw[1] &= keep; raw[2] &= keep; raw[3] &= keep;
+      Fa3AW<R + 0>::w(raw[0]); Fa3AW<R + 1>::w(raw[1]); Fa3AW<R + 2>::w(raw[2]); Fa3AW<R + 3>::w(raw[3]);
+    });
+    asm volatile("s_nop 7" ::: "memory");  // accumulator-file writes settle before the first MFMA reads them
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW) : "memory");  // tiles 0 and 1 have landed, tile 2 may still fly
     __syncthreads();
+    if constexpr (STAMP) pt2 = __builtin_amdgcn_s_memtime();
 
     f32x16_t S[2][QT][2];   // score tiles: buffer (t & 1), query sub-tile, 32-key half
     u32x4_t pfw[QT][4];     // P^T fragments of the tile in phase 2: k-step s (16 keys)
@@ -598,21 +614,25 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
             S[nb][qt][0][i] -= delta;
             S[nb][qt][1][i] -= delta;
           }
-          auto rescale = [&](auto KI) {
-            constexpr int k = decltype(KI)::value;
-            f32x4_t v[4] = {Fa2AccIO<k>::template read4<0>(), Fa2AccIO<k>::template read4<1>(),
-                            Fa2AccIO<k>::template read4<2>(), Fa2AccIO<k>::template read4<3>()};
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[gq][e] *= alpha;
-            Fa2AccIO<k>::template write4<0>(v[0]);
-            Fa2AccIO<k>::template write4<1>(v[1]);
-            Fa2AccIO<k>::template write4<2>(v[2]);
-            Fa2AccIO<k>::template write4<3>(v[3]);
-          };
-          fa2_for<DT_>([&](auto DTI) { rescale(IC(FA3_T_O + qt * DT_ + decltype(DTI)::value)); });
-          rescale(IC(FA3_T_L + qt));
+          // (alpha = 1 in every lane -- the first tile of a pass without carried state, or a trigger caused by the
+          //  other sub-tile -- leaves O and L as they are: skip the pass over the accumulator file)
+          if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+            auto rescale = [&](auto KI) {
+              constexpr int k = decltype(KI)::value;
+              f32x4_t v[4] = {Fa2AccIO<k>::template read4<0>(), Fa2AccIO<k>::template read4<1>(),
+                              Fa2AccIO<k>::template read4<2>(), Fa2AccIO<k>::template read4<3>()};
+  #pragma unroll
+              for (int gq = 0; gq < 4; ++gq)
+  #pragma unroll
+                for (int e = 0; e < 4; ++e) v[gq][e] *= alpha;
+              Fa2AccIO<k>::template write4<0>(v[0]);
+              Fa2AccIO<k>::template write4<1>(v[1]);
+              Fa2AccIO<k>::template write4<2>(v[2]);
+              Fa2AccIO<k>::template write4<3>(v[3]);
+            };
+            fa2_for<DT_>([&](auto DTI) { rescale(IC(FA3_T_O + qt * DT_ + decltype(DTI)::value)); });
+            rescale(IC(FA3_T_L + qt));
+          }
           negref[qt] = -ref_new;
         });
         asm volatile("s_nop 7" ::: "memory");
@@ -658,6 +678,7 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
         st_sum[0] += c2 - c1; st_sum[1] += c2b - c2; st_sum[2] += c3 - c2b; st_sum[3] += c4 - c3; st_sum[4] += c5 - c4;
       }
     };
+    if constexpr (STAMP) pt3 = __builtin_amdgcn_s_memtime();
     int t = 0;
     for (; t + 1 < n_w; t += 2) {
       iter(t, IC(0));
@@ -673,11 +694,17 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be writing LDS when the next pass starts / the wave ends
 
-    if constexpr (STAMP) {  // p.mask doubles as the stamp buffer: [block][wave][8] u64 (last pass wins)
-      if (lane == 0 && p.mask != nullptr) {
-        unsigned long long* d = (unsigned long long*)p.mask + ((size_t)blockIdx.x * 4 + wave) * 8;
-        d[0] = st_sum[0]; d[1] = st_sum[1]; d[2] = st_sum[2]; d[3] = st_sum[3]; d[4] = st_sum[4]; d[5] = n_w; d[6] = n_tiles;
-      }
+    if constexpr (STAMP) {
+      pt4 = __builtin_amdgcn_s_memtime();
+      st_all[8] += pt1 - pt0;   // state init
+      st_all[9] += pt2 - pt1;   // first K/V tiles and Q requested and landed, accumulator-file set-up
+      st_all[10] += pt3 - pt2;  // tile 0 scores / masks / max
+      st_all[11] += pt4 - pt3;  // tile loop + helper iterations + drain
+      st_all[12] -= pt4;        // (+ end of epilogue below)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) st_all[i] += st_sum[i];
+      st_all[5] += n_w;
+      st_all[6] += n_tiles;
     }
     // ---- epilogue
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMAs retired before the accumulator file is read
@@ -717,6 +744,18 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
         }
       });
     });
+    if constexpr (STAMP) st_all[12] += __builtin_amdgcn_s_memtime();  // epilogue
   }  // pass
+  if constexpr (STAMP) {  // p.mask doubles as the stamp buffer: [block][wave][16] u64; [7] = whole workgroup lifetime
+    if (lane == 0 && p.mask != nullptr) {
+      unsigned long long* d = (unsigned long long*)p.mask + ((size_t)blockIdx.x * 4 + wave) * 16;
+      const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+#pragma unroll
+      for (int i = 0; i < 7; ++i) d[i] = st_all[i];
+      d[7] = t_end - st_all[7];
+#pragma unroll
+      for (int i = 8; i < 13; ++i) d[i] = st_all[i];
+    }
+  }
 #undef IC
 }

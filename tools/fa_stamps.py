@@ -9,7 +9,7 @@ causal = (sys.argv[1] == "causal") if len(sys.argv) > 1 else False
 B, S, H, D = 8, 4096, 16, 64
 nblk = (S + 255) // 256
 grid = B * H * ((nblk + 1) // 2 if causal else nblk)
-dbg = torch.zeros(grid * 4 * 8, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(grid * 4 * 16, dtype=torch.int64, device="cuda")
 os.environ["MIO_FA_DBG_PTR"] = str(dbg.data_ptr())
 os.environ["MIO_FA_IMPL"] = "3"
 from mio import ops
@@ -18,14 +18,22 @@ q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16) for _ in
 for _ in range(300):
     ops.fa3_fwd(q, k, v, causal=causal)
 torch.cuda.synchronize()
-d = dbg.view(grid, 4, 8).cpu().double()
+d = dbg.view(grid, 4, 16).cpu().double()
+d = d[d[:, 0, 7] > 0]  # persistent launch: only gridDim.x workgroups write a record
+print(f"{d.shape[0]} workgroups, {d[..., 6].mean().item():.0f} tiles walked per workgroup")
 nw = d[..., 5].clamp_min(1)
 names = ["phase1 QK||exp", "edge masks", "phase2 PV||max||dma", "update", "wait+barrier"]
 tot = 0
 for i, n in enumerate(names):
     per = (d[..., i] / nw).mean().item()
     tot += per
-    print(f"{n:16s} {per:8.0f} cycles per tile (per wave, mean over waves; tiles of the last pass)")
+    print(f"{n:16s} {per:8.0f} cycles per tile (per wave, mean over waves; both passes)")
 print(f"{'sum':16s} {tot:8.0f}")
+life = d[..., 7].mean().item()
+inloop = d[..., :5].sum(-1).mean().item()
+print(f"workgroup lifetime {life:9.0f} cycles, of which in the tile loop {inloop:9.0f} ({100 * inloop / life:.1f} %); "
+      f"outside (Q load, first tiles, epilogue, helper iterations) {life - inloop:9.0f}")
+for i, n in enumerate(["Q load + state init", "first K/V tiles land", "tile 0 scores/max", "tile loop + helpers + drain", "epilogue"]):
+    print(f"  {n:28s} {d[..., 8 + i].mean().item():9.0f} cycles per workgroup (all passes)")
 for w in range(4):
     print(f"  wave {w}: " + "  ".join(f"{(d[:, w, i] / nw[:, w]).mean().item():7.0f}" for i in range(5)), " n_w", nw[:, w].mean().item())
