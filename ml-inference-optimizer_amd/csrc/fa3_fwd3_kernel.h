@@ -727,17 +727,30 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
         constexpr int k = FA3_T_O + qt * DT_ + dt;
         const f32x4_t v[4] = {Fa2AccIO<k>::template read4<0>(), Fa2AccIO<k>::template read4<1>(),
                               Fa2AccIO<k>::template read4<2>(), Fa2AccIO<k>::template read4<3>()};
+        // 16-bit output: the two lanes of a row (h = 0 / 1) hold d = 8g + 4h .. +3 -- one v_permlane32_swap per word
+        // gives lane h the 8 contiguous columns 16 gp + 8h .. +7 of g pair gp: 16-byte stores instead of 8-byte ones
+        if (op != nullptr) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d0 = 32 * dt + 8 * g + 4 * h;
-          if (q_ok[qt] && d0 < p.D) {
-            const float x0 = v[g][0] * inv, x1 = v[g][1] * inv, x2 = v[g][2] * inv, x3 = v[g][3] * inv;
-            if (op != nullptr) {
-              u32x2_t w = {pack2<T>(x0, x1), pack2<T>(x2, x3)};
-              *(u32x2_t*)(op + d0) = w;
+          for (int gp = 0; gp < 2; ++gp) {
+            uint32_t w[2][2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const f32x4_t x = v[2 * gp + k];
+              w[k][0] = pack2<T>(x[0] * inv, x[1] * inv);
+              w[k][1] = pack2<T>(x[2] * inv, x[3] * inv);
             }
-            if (oa != nullptr) {
-              f32x4_t w = {x0, x1, x2, x3};
+            const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+            const int d0 = 32 * dt + 16 * gp + 8 * h;
+            if (q_ok[qt] && d0 < p.D) *(u32x4_t*)(op + d0) = (u32x4_t){s0[0], s1[0], s0[1], s1[1]};
+          }
+        }
+        if (oa != nullptr) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int d0 = 32 * dt + 8 * g + 4 * h;
+            if (q_ok[qt] && d0 < p.D) {
+              const f32x4_t w = {v[g][0] * inv, v[g][1] * inv, v[g][2] * inv, v[g][3] * inv};
               *(f32x4_t*)(oa + d0) = w;
             }
           }
