@@ -336,60 +336,75 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
     // ---- K/V staging: global -> LDS by DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB of lane-linear LDS per
     // wave-instruction, no staging registers).  A stage is 17 such units: 0..8 the K tile (64 rows x 144 B: 9 chunks
     // per row, the 9th is padding), 9..16 the V tile ([key/8][d/32][8][32] sub-tiles of 512 B); the per-lane SOURCE
-    // address realises the layout.  Wave w moves units w, w+4, w+8, w+12 and a fifth (16 for wave 0, its first unit
-    // again for the others: every wave then has exactly 5 loads per tile in flight, which is what the counted
-    // waits below assume).  Rows past Sk and chunks
+    // address realises the layout.  Every wave moves exactly UPW = 5 units per tile (slot assignment below; spare
+    // slots repeat the wave's first unit), which is what the counted waits assume.  Rows past Sk and chunks
     // past D are clamped to valid data instead of zeroed: such keys are masked to -inf (edge tiles) and Q~ is zero
     // past D, so the values only need to be finite.
     const T* kbase = (const T*)p.k + b * p.ks_b + kvh * p.ks_h;
     const T* vbase = (const T*)p.v + b * p.vs_b + kvh * p.vs_h;
     const int d_chunks = p.D >> 3;
-    int st_row[UPW], st_cb[UPW];  // per unit slot: key row inside the tile, byte offset of the 16-B chunk in the row
+    // Slot i of a wave: slots 0 .. KSL-1 carry K units (wave + 4i; the spare ones of the last K slot repeat the wave's
+    // first unit), the rest V units -- K or V is a compile-time property of the slot, and so is its LDS offset from
+    // the wave's first unit (bar the repeat).  Per-lane source offsets (row * stride + chunk) are fixed for the whole
+    // kernel; only the last tile of the sequence can be partial, and it gets its own set with the rows clamped to the
+    // last valid one.  What is left per unit in the tile loop: one select, m0, the load (was ~12 instructions: on a
+    // one-wave-per-SIMD kernel every scalar instruction is issue time, and phase 2 is issue-bound).
+    constexpr int KSL = (MAP::KU + 3) / 4;
+    const int ks2 = (int)p.ks_s * 2, vs2 = (int)p.vs_s * 2;  // row strides in bytes
+    const int last_tile = (p.Sk - 1) >> 6, last_row = (p.Sk - 1) & (FA_BN - 1);
+    int st_off[UPW], st_offl[UPW];  // per slot: byte offset of this lane's 16-B chunk from the tile's first row (full / last tile)
 #pragma unroll
     for (int i = 0; i < UPW; ++i) {
-      const int u = (wave + 4 * i < MAP::NU) ? wave + 4 * i : wave;  // UPW units per wave (spare slots repeat the first)
-      int row, c;
-      if (u < MAP::KU) {
+      int u, row, c;
+      if (i < KSL) {
+        u = (wave + 4 * i < MAP::KU) ? wave + 4 * i : wave;
         const int u16 = 64 * u + lane;
         row = u16 / MAP::CPRK;
         c = u16 % MAP::CPRK;
       } else {
-        const int blk = 2 * (u - MAP::KU) + (lane >> 5);
+        u = wave + 4 * (i - KSL);
+        const int blk = 2 * u + (lane >> 5);
         row = 8 * (blk / DT_) + ((lane & 31) >> 2);
         c = 4 * (blk % DT_) + (lane & 3);
       }
       c = c < d_chunks ? c : d_chunks - 1;
-      st_row[i] = row;
-      st_cb[i] = 16 * c;
+      const int rowl = row < last_row ? row : last_row;
+      st_off[i] = row * (i < KSL ? ks2 : vs2) + 16 * c;
+      st_offl[i] = rowl * (i < KSL ? ks2 : vs2) + 16 * c;
     }
+    const int kl_imm = (wave + 4 * (KSL - 1) < MAP::KU) ? 4096 * (KSL - 1) : 0;  // LDS offset of the last K slot's unit
     // one DMA unit of tile `tile` (clamped to the last tile: a run past the end re-fetches valid data into a dead
     // stage, which keeps the number of loads per iteration -- and the counted waits -- the same for every iteration)
-    const int ks2 = (int)p.ks_s * 2, vs2 = (int)p.vs_s * 2;  // row strides in bytes (< 2^24: 24-bit multiplies below)
     const char* dma_kb = nullptr;  // scalar: first row of the K / V tile being fetched (set by dma_tile_base)
     const char* dma_vb = nullptr;
-    int dma_last = 0;
+    bool dma_is_last = false;      // that tile is the (possibly partial) last one of the sequence
+    uint32_t dma_lds = 0;          // LDS address of this wave's first unit in the stage being filled
     auto dma_tile_base = [&](int tile_) {
       const int tile = tile_ < n_tiles_dma ? tile_ : n_tiles_dma - 1;
       const int kv0 = tile * FA_BN;
       dma_kb = (const char*)(kbase + (int64_t)kv0 * p.ks_s);
       dma_vb = (const char*)(vbase + (int64_t)kv0 * p.vs_s);
-      dma_last = p.Sk - 1 - kv0;  // last valid row of the tile (>= 63 for a full tile)
+      dma_is_last = (tile == last_tile);
+      dma_lds = (uint32_t)(size_t)((MIO_LDS char*)(smem + (tile_ & (FA3_STAGES - 1)) * SM::STAGE)) + 1024 * wave;
     };
-    auto dma_unit = [&](auto I_, int tile_) {
+    auto dma_unit = [&](auto I_, int) {
       constexpr int i = decltype(I_)::value;
-      const int stage = tile_ & (FA3_STAGES - 1);
-      const int u = (wave + 4 * i < MAP::NU) ? wave + 4 * i : wave;  // wave-uniform
-      const bool isk = u < MAP::KU;
-      const char* base = isk ? dma_kb : dma_vb;
-      const int row = st_row[i] < dma_last ? st_row[i] : dma_last;  // rows past Sk: clamped (branch-free)
-      const int off = (int)__umul24((unsigned)row, (unsigned)(isk ? ks2 : vs2)) + st_cb[i];
+      const int off = dma_is_last ? st_offl[i] : st_off[i];
+      const char* base = (i < KSL) ? dma_kb : dma_vb;
       // asm: invisible to the compiler's wait-count insertion, which otherwise drains the DMA (vmcnt(0)) in front of
       // the next LDS read it cannot prove disjoint -- the V fragments of the tile being computed
-      const uint32_t lds = (uint32_t)(size_t)((MIO_LDS char*)(smem + stage * SM::STAGE + 1024 * u));
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                   :
-                   : "s"(lds), "v"(off), "s"(base)
-                   : "memory", "m0");
+      if constexpr (i == KSL - 1) {
+        asm volatile("s_add_i32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                     :
+                     : "s"(dma_lds), "s"(kl_imm), "v"(off), "s"(base)
+                     : "memory", "m0", "scc");  // s_add writes SCC
+      } else {
+        constexpr int imm = i < KSL ? 4096 * i : 1024 * MAP::KU + 4096 * (i - KSL);
+        asm volatile("s_add_i32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                     :
+                     : "s"(dma_lds), "n"(imm), "v"(off), "s"(base)
+                     : "memory", "m0", "scc");  // s_add writes SCC
+      }
     };
     auto stage_dma = [&](int tile) {
       dma_tile_base(tile);
