@@ -218,6 +218,42 @@ FA3_OPS(__bf16, "bf16")
 FA3_OPS(_Float16, "f16")
 #undef FA3_OPS
 
+// Phase 2 gives every micro-step (= one MFMA, 32 matrix-pipe cycles of which the issue port is held for 8) exactly ONE
+// piece of side work, so that the step stays inside the MFMA's shadow: the V fragment read of the next k-step (3 steps,
+// fixed by the fragment ring), one of the 16 scale / max groups (4 fma + 2 max3 = 24 issue cycles), or one DMA unit.
+// Stacked on the same step (as they were: scale / max on steps 2..17, reads on 1 / 7 / 13, DMA on every fourth) the
+// dense steps overflow the shadow and the matrix pipe waits.  role(j): 0 nothing, 1 + i scale / max group i,
+// 32 + k DMA unit k.  Order: a DMA unit first, then four groups and a unit alternately, the remaining units last.
+template <int NS2, int PS, int UPW>
+struct Fa3P2Role {
+  static constexpr int role(int j) {
+    int n_v = 0, n_d = 0;
+    for (int jj = 0; jj < NS2; ++jj) {
+      const int s = jj / PS, m = jj % PS;
+      const bool rd = (m == 1 && s + 1 < 4);
+      int r = 0;
+      if (!rd) {
+        const bool want_d = n_d < UPW && (n_d == 0 || n_v >= 4 * n_d || n_v == 16);
+        if (want_d) {
+          r = 32 + n_d;
+          ++n_d;
+        } else if (n_v < 16) {
+          r = 1 + n_v;
+          ++n_v;
+        }
+      }
+      if (jj == j) return r;
+    }
+    return 0;
+  }
+  static constexpr int count(int lo, int hi) {  // steps with a role in [lo, hi)
+    int n = 0;
+    for (int jj = 0; jj < NS2; ++jj) n += (role(jj) >= lo && role(jj) < hi) ? 1 : 0;
+    return n;
+  }
+  static_assert(count(1, 17) == 16 && count(32, 32 + UPW) == UPW, "phase 2: not every scale/max group or DMA unit has a step");
+};
+
 template <typename T, int D, bool CAUSAL, bool STAMP = false>
 __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
   using X8 = typename DT<T>::x8;
@@ -560,7 +596,7 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       constexpr int nb = decltype(NB_)::value;
       constexpr bool DO_PV = decltype(DO_PV_)::value != 0;
       constexpr int PS = 2 * DT_ + 2, NS2 = 4 * PS;  // per 16-key k-step: 2 DT PV MFMAs + 2 row-sum MFMAs
-      constexpr int DSTEP = (NS2 - 4) / UPW;          // one DMA unit every DSTEP steps
+      using ROLE = Fa3P2Role<NS2, PS, UPW>;
       auto step = [&](auto J_) {
         constexpr int j = decltype(J_)::value;
         constexpr int s = j / PS, m = j % PS;
@@ -574,12 +610,12 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
             OPS::template lsum1<FA3_A_ONES>(__builtin_bit_cast(X8, pfw[1][s]));
           }
           if constexpr (m == 1 && s + 1 < 4) read_v(vb, IC(s + 1));  // slot (s+1)&1 was last read by k-step s-1
-          if constexpr (j >= 3 && (j - 3) % DSTEP == 0 && (j - 3) / DSTEP < UPW) dma_unit(IC((j - 3) / DSTEP), dma_tile);
+          if constexpr (ROLE::role(j) >= 32) dma_unit(IC(ROLE::role(j) - 32), dma_tile);
         }
-        // scale-and-subtract + max of 4 scores per step (steps 2..17), in the order the QK^T MFMAs of phase 1 finished
-        // writing them: sub-tile qt = i / 8, 32-key half tt = (i / 4) & 1, registers 4 (i & 3) .. +3
-        if constexpr (j >= 2 && j < 18) {
-          constexpr int i = j - 2, qt = i / 8, tt = (i / 4) & 1, r0 = 4 * (i & 3);
+        // scale-and-subtract + max of 4 scores per group, in the order the QK^T MFMAs of phase 1 finished writing
+        // them: sub-tile qt = i / 8, 32-key half tt = (i / 4) & 1, registers 4 (i & 3) .. +3
+        if constexpr (ROLE::role(j) >= 1 && ROLE::role(j) <= 16) {
+          constexpr int i = ROLE::role(j) - 1, qt = i / 8, tt = (i / 4) & 1, r0 = 4 * (i & 3);
           // single-instruction fmas: left to the compiler, adjacent scalar fmas are SLP-packed into v_pk_fma_f32, which
           // costs more issue time beside MFMAs than the two scalar forms (MI355X_MICROARCH.md, packed f32 VALU)
           auto fma1 = [&](float x) {
