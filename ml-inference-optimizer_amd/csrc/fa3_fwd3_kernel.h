@@ -561,7 +561,8 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
             pfw[qt][s][2 * half + 0] = w0;
             pfw[qt][s][2 * half + 1] = w1;
           }
-          if constexpr (j == NS1 - 1) read_v(vb, IC(0));
+          // (the first V fragments of phase 2, early: issued in the last step their LDS latency opens phase 2)
+          if constexpr (j == NS1 / 2) read_v(vb, IC(0));
         }
         __builtin_amdgcn_sched_barrier(0);
       };
