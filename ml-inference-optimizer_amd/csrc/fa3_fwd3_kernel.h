@@ -617,12 +617,12 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
         // them: sub-tile qt = i / 8, 32-key half tt = (i / 4) & 1, registers 4 (i & 3) .. +3
         if constexpr (ROLE::role(j) >= 1 && ROLE::role(j) <= 16) {
           constexpr int i = ROLE::role(j) - 1, qt = i / 8, tt = (i / 4) & 1, r0 = 4 * (i & 3);
-          // single-instruction fmas: left to the compiler, adjacent scalar fmas are SLP-packed into v_pk_fma_f32, which
-          // costs more issue time beside MFMAs than the two scalar forms (MI355X_MICROARCH.md, packed f32 VALU)
+          // scalar fmas: this translation unit is compiled with -fno-slp-vectorize -- SLP packs adjacent scalar fmas into
+          // v_pk_fma_f32, which costs more issue time beside MFMAs than the two scalar forms (MI355X_MICROARCH.md,
+          // packed f32 VALU); written as single-instruction asm instead, hipcc puts an s_nop between each group's
+          // fmas and the max that reads them (4 of the step's 32 cycles)
           auto fma1 = [&](float x) {
-            float d;
-            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(c2), "v"(negref[qt]));
-            return d;
+            return __builtin_fmaf(x, c2, negref[qt]);
           };
           float v0 = fma1(S[nb][qt][tt][r0 + 0]);
           float v1 = fma1(S[nb][qt][tt][r0 + 1]);

@@ -277,7 +277,7 @@ def test_fwd3_accumulator_registers_untouched_by_compiler(tmp_path, type_id, D):
     csrc = os.path.join(ROOT, "ml-inference-optimizer_amd", "csrc")
     isa = tmp_path / "fa.s"
     subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I../../include", "-I.", "-Wno-unused-value",
-                    "-mllvm", "-amdgpu-mfma-vgpr-form", f"-DFA_TYPE_ID={type_id}", f"-DFA_D={D}", "-S",
+                    "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize", f"-DFA_TYPE_ID={type_id}", f"-DFA_D={D}", "-S",
                     "--cuda-device-only", "fa3_fwd_inst.hip", "-o", str(isa)], cwd=csrc, check=True, capture_output=True)
     text = isa.read_text().splitlines()
     starts = [i for i, l in enumerate(text) if re.match(r"^_Z15fa3_fwd3_kernel\w+:", l)]
@@ -306,7 +306,7 @@ def test_fwd2_accumulator_registers_untouched_by_compiler(tmp_path, D):
     csrc = os.path.join(ROOT, "ml-inference-optimizer_amd", "csrc")
     isa = tmp_path / "fa.s"
     subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I../../include", "-I.", "-Wno-unused-value",
-                    "-mllvm", "-amdgpu-mfma-vgpr-form", "-DFA_TYPE_ID=0", f"-DFA_D={D}", "-S", "--cuda-device-only",
+                    "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize", "-DFA_TYPE_ID=0", f"-DFA_D={D}", "-S", "--cuda-device-only",
                     "fa3_fwd_inst.hip", "-o", str(isa)], cwd=csrc, check=True, capture_output=True)
     text = isa.read_text().splitlines()
     starts = [i for i, l in enumerate(text) if re.match(r"^_Z15fa3_fwd2_kernel\w+:", l)]
