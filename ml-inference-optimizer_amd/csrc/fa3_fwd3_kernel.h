@@ -418,8 +418,12 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
     auto dma_tile_base = [&](int tile_) {
       const int tile = tile_ < n_tiles_dma ? tile_ : n_tiles_dma - 1;
       const int kv0 = tile * FA_BN;
-      dma_kb = (const char*)(kbase + (int64_t)kv0 * p.ks_s);
-      dma_vb = (const char*)(vbase + (int64_t)kv0 * p.vs_s);
+      // (32-bit offsets: the launcher sends sequences whose K / V rows span 4 GiB or more to fa3_fwd_kernel; 8
+      //  scalar instructions per 64-bit multiply-add otherwise, and scalar instructions are issue time here)
+      const uint32_t ko = __builtin_amdgcn_readfirstlane((uint32_t)kv0 * (uint32_t)ks2);
+      const uint32_t vo = __builtin_amdgcn_readfirstlane((uint32_t)kv0 * (uint32_t)vs2);
+      dma_kb = (const char*)kbase + ko;
+      dma_vb = (const char*)vbase + vo;
       dma_is_last = (tile == last_tile);
       dma_lds = (uint32_t)(size_t)((MIO_LDS char*)(smem + (tile_ & (FA3_STAGES - 1)) * SM::STAGE)) + 1024 * wave;
     };

@@ -88,7 +88,9 @@ int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t
   //     D64 causal 0.359 ms (766 TFLOP/s) vs 0.442 two-waves-per-SIMD / 0.52 sequential one-wave; non-causal 0.626 vs 0.79;
   //     D128 causal 0.284 ms (967 TFLOP/s) vs 0.361 sequential one-wave; D80 non-causal 0.828 ms (830) vs 1.158;
   //   user masks and Sq <= 128: the two-waves-per-SIMD kernel.
-  if ((fa_impl() == 3 || fa_impl() == 0) && mask_kind == MIO_MASK_NONE && p.Sq > 128)
+  // (the pipelined kernel addresses K / V tiles with 32-bit byte offsets from the (batch, head) base)
+  const bool span32 = (int64_t)p.Sk * p.ks_s * 2 < (1ll << 32) && (int64_t)p.Sk * p.vs_s * 2 < (1ll << 32);
+  if ((fa_impl() == 3 || fa_impl() == 0) && mask_kind == MIO_MASK_NONE && p.Sq > 128 && span32)
     return causal ? launch_three<true>(p, stream) : launch_three<false>(p, stream);
   const bool two = (fa_impl() == 2);
   if (mask_kind == MIO_MASK_NONE && two && p.Sq > 128)
