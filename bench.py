@@ -2,22 +2,30 @@
 """Headline benchmark: forward tokens/s of the GPT-2-shaped stack (d=1024, H=16, L=24, S=4096, B=8 per GPU,
 bf16, causal FA3 + FusedMLP) on N MI355X, plus the roofline of the dominant kernel and the CPU baseline.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
+        N = 1: runs in this process.  N > 1 without a launcher (WORLD_SIZE unset): this process touches no GPU, starts
+        N child processes (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and relays rank 0's line.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W          (the driver's form: same code path in every rank)
 
 One "step" = one forward of the whole stack over one synthetic batch resident in HBM.  tokens/s =
-B*S / avg latency (reference benchmarks/runners.py:356-358).  N > 1: one process per GPU, the batch
-dimension is sharded (independent sequences, no data-path collective) -> weak scaling.  With --parallel-extras
-the tensor-parallel (config 3) and ring-attention (config 4) exchange paths are also measured after the timed
-region and reported under "extra" (strong-scaling measurements of the same global work); they are opt-in because
-a collective that hangs there would take the headline line down with it.
+B*S / avg latency (reference benchmarks/runners.py:356-358).  N > 1: one process per GPU over RCCL, the batch
+dimension is sharded (independent sequences, no data-path collective) -> weak scaling; `ranks_seen` is an all-reduce
+of ones over the job.  After the timed region, under "extra" (never inside it, never part of `value`):
+  N = 1: paged decode (HBM roofline), the C5 workload (non-causal cross attention d 1280 / Dh 80 + FusedMLP-GELU);
+  N > 1: BASELINE configs 3 and 4 -- the tensor-parallel stack (tp 2 and 4: RCCL all-reduce over xGMI, overlapped
+         with the row-parallel GEMM vs not) and ring attention at S 65 536 over the N ranks (K/V exchange overlapped
+         with the attention kernel vs not).  Each leg is fenced by try/except and a watchdog: a collective that hangs
+         costs the leg, not the headline line.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,17 +33,53 @@ for _p in (ROOT, os.path.join(ROOT, "ml-inference-optimizer_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
+METRIC = "forward tokens/sec GPT-2 d=1024 seq=4096 at 1/2/4/8 MI355X; % MFMA roofline"
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` (N > 1, no launcher) -> N ranks
+# ----------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """Parent of a self-launched job: never initialises the GPU; starts one fresh child per rank, relays rank 0's
+    stdout (the JSON line), sends the other ranks' stdout to stderr, returns the worst exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = None if r == 0 else sys.stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    try:
+        for p in procs:
+            p.wait()
+            rc = max(rc, abs(p.returncode))
+            if p.returncode != 0:  # one rank failed: the others would wait in a collective forever
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------
 def _events_ms(fn, iters, warmup=3, sustain_ms=200.0):
     """Average duration of fn() in ms, HIP events on the stream the kernels are launched on
     (ops.* launch on torch's current stream).  Launches are queued back to back for `sustain_ms` before and
     during the timed region so the chip sits at the sustained clock / power point it holds inside the model."""
+    import torch
+
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -61,6 +105,7 @@ def kernel_rooflines(model, x, iters=10):
     benchmark stack, so the operand statistics -- and with them the clock the chip holds -- are the model's own),
     HIP events on the launch stream -> which kernel dominates and its achieved fraction of the MFMA roofline
     (algorithmic FLOPs: SURVEY.md 8d / BASELINE.md section 4)."""
+    import torch
     from mio import ops
 
     blk = model.h[0]
@@ -101,6 +146,57 @@ def kernel_rooflines(model, x, iters=10):
     return out
 
 
+def decode_leg(dt):
+    """Paged decode step: B 64, H 16, D 64, context 4096, block 16 -- 1 GiB of K/V cache, streams from
+    HBM.  Bound: HBM.  Algorithmic bytes = 2 * B * ctx * Hkv * D * 2 (every cached K and V element once)."""
+    import torch
+    from mio import ops
+
+    Bd, Hd, Dd, bs, ctx = 64, 16, 64, 16, 4096
+    nblk = Bd * ctx // bs
+    kc = torch.randn(nblk, 1, bs, Hd, Dd, device="cuda", dtype=dt)
+    vc = torch.randn(nblk, 1, bs, Hd, Dd, device="cuda", dtype=dt)
+    bt = torch.randperm(nblk, device="cuda").view(Bd, -1).to(torch.int32)
+    cl = torch.full((Bd,), ctx, device="cuda", dtype=torch.int32)
+    q = torch.randn(Bd, Hd, 1, Dd, device="cuda", dtype=dt)
+    o = torch.empty_like(q)
+    ms = _events_ms(lambda: ops.paged_attention_forward(q, o, kc, vc, bt, cl, bs, ctx, 0), 20, sustain_ms=100.0)
+    nbytes = 2.0 * Bd * ctx * Hd * Dd * 2
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"workload": f"paged decode q_len 1, B {Bd} H {Hd} D {Dd} ctx {ctx} block {bs} (random physical blocks)",
+            "kernel": "decode_paged_kernel + decode_reduce_kernel", "bound": "hbm", "ms": ms, "achieved": gbs,
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "bytes_per_launch": nbytes,
+            "tokens_per_s": Bd / (ms * 1e-3)}
+
+
+def c5_leg(dt, steps=3):
+    """BASELINE configs[4]: diffusion-style non-causal cross attention d 1280 (H 16 -> Dh 80), Sq = Sk = 4096, +
+    FusedMLP-GELU I 5120; 4 blocks, B 8, context from a separate [B, Sk, d] tensor."""
+    import torch
+    from mio.synthetic import CrossAttentionStack
+
+    B, S, d, H, L = 8, 4096, 1280, 16, 4
+    I = 4 * d
+    model = CrossAttentionStack(d, H, L, I, "bf16", seed=0).to(device="cuda", dtype=dt).eval()
+    torch.manual_seed(7)
+    x = torch.randn(B, S, d, device="cuda", dtype=dt)
+    ctx = torch.randn(B, S, d, device="cuda", dtype=dt)
+    with torch.no_grad():
+        model(x, ctx)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model(x, ctx)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+    flops = L * (4.0 * B * S * S * d + 8.0 * B * S * d * d + 4.0 * B * S * d * I)
+    del model
+    torch.cuda.empty_cache()
+    return {"workload": f"cross-attention blocks d={d} h={H} (Dh 80) Sq=Sk={S} B={B} L={L} non-causal + FusedMLP(gelu) I={I}",
+            "ms_per_step": el * 1e3, "tokens_per_s": B * S / el, "model_tflops": flops / el / 1e12,
+            "mfma_roofline_frac": flops / el / 1e12 / PEAK_BF16_TFLOPS}
+
+
 def cpu_baseline(d, H, S):
     """Reference CPU path (baseline/inference.py BasicInferenceRunner semantics, oracle port) on this host's
     cores, on a bounded sample: 2 layers, B=1 of the same S/d/H; reported as full-stack-equivalent tokens/s."""
@@ -109,6 +205,43 @@ def cpu_baseline(d, H, S):
     layers = 2
     r = time_cpu_baseline(hidden_size=d, num_heads=H, num_layers=layers, batch=1, seq_len=S, warmup=1, iters=2)
     return r, layers
+
+
+def cpu_baseline_c1():
+    """BASELINE configs[0]: GPT-2-small shape (d 768, h 12, L 12) seq 128 B 1 through the BasicInferenceRunner port."""
+    from oracle.baseline_runner import time_cpu_baseline
+
+    r = time_cpu_baseline(hidden_size=768, num_heads=12, num_layers=12, batch=1, seq_len=128, warmup=2, iters=5)
+    return {"value": r["tokens_per_s"], "unit": "tokens/s", "cores": r["threads"], "kind": "port",
+            "sample": "GPT-2-small-shaped block stack d=768 h=12 L=12, B=1 S=128, fp32, 2 warm-up + 5 timed forwards "
+                      "(hidden states in / out: no embedding or LM head)", "avg_latency_ms": r["avg_latency_s"] * 1e3}
+
+
+class Watchdog:
+    """If a fenced leg does not finish in `seconds`, rank 0 prints the line it has (with the leg marked) and every rank
+    leaves: a hung collective cannot be cancelled from Python."""
+
+    def __init__(self, rank, res):
+        self.rank, self.res, self.timer, self.leg, self.printed = rank, res, None, None, False
+
+    def arm(self, leg, seconds):
+        self.disarm()
+        self.leg = leg
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def _fire(self):
+        if self.rank == 0 and not self.printed:
+            self.res.setdefault("extra", {})[self.leg] = {"error": "timed out (collective did not complete)"}
+            sys.stdout.write(json.dumps(self.res) + "\n")
+            sys.stdout.flush()
+        os._exit(0 if self.rank == 0 else 3)
 
 
 def main():
@@ -121,30 +254,46 @@ def main():
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--heads", type=int, default=16)
     ap.add_argument("--layers", type=int, default=24)
-    ap.add_argument("--no-extra", action="store_true", help="skip the roofline / cpu-baseline legs (N = 1)")
-    ap.add_argument("--parallel-extras", action="store_true",
-                    help="N > 1: also time the tensor-parallel and ring-attention paths (RCCL collectives)")
+    ap.add_argument("--no-extra", action="store_true", help="only the headline line: no roofline / cpu / extra legs")
+    ap.add_argument("--ring-seq", type=int, default=65536, help="N > 1: total sequence length of the ring-attention leg")
     a = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a.gpus))
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("MIO_BENCH_BACKEND", "nccl")  # "gloo": single-GPU rehearsal of the N > 1 plumbing
+        tmo = datetime.timedelta(seconds=300)
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=tmo,
+                                    device_id=torch.device("cuda", local_rank))
         else:
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
     else:
         torch.cuda.set_device(0)
     N = world
     dev, dt = "cuda", torch.bfloat16
     B, S, d, H, L = a.batch, a.seq, a.hidden, a.heads, a.layers
     I = 4 * d
+    cdev = dev if backend in (None, "nccl") else "cpu"  # where small control tensors of a collective live
+
+    ranks_seen = 1
+    if N > 1:
+        one = torch.ones(1, device=cdev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
 
     from mio.synthetic import GPT2ShapedStack
 
@@ -168,7 +317,7 @@ def main():
         sync_all()
         elapsed = time.perf_counter() - t0
     if N > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = elapsed / a.steps * 1e3
@@ -176,7 +325,7 @@ def main():
     flops_step = L * (2.0 * B * S * (S + 1) * d + 8.0 * B * S * d * d + 4.0 * B * S * d * I)
 
     res = {
-        "metric": "forward tokens/sec GPT-2 d=1024 seq=4096 at 1/2/4/8 MI355X; % MFMA roofline",
+        "metric": METRIC,
         "value": tokens_per_s,
         "unit": "tokens/s",
         "n_gpus": N,
@@ -190,9 +339,12 @@ def main():
         "data": "synthetic (random-init weights N(0,0.02), hidden states N(0,1), seed 0)",
         "config": {"workload": f"GPT-2-shaped block stack d={d} h={H} L={L} seq={S} B={B}/GPU causal FA3+FusedMLP(gelu) forward",
                    "global_batch": B * N, "seq_len": S, "parallelism": f"dp{N}" if N > 1 else "single"},
+        "ranks_seen": ranks_seen,
+        "backend": backend or "none",
         "model_tflops_per_gpu": flops_step / (ms_per_step * 1e-3) / 1e12,
         "mfma_roofline_frac_end_to_end": flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
     }
+    dog = Watchdog(rank, res)
 
     if not a.no_extra and rank == 0 and N == 1:
         try:
@@ -202,15 +354,18 @@ def main():
             kd = ks[dom]
             per_launch_ms = kd["ms"] / kd["launches"]
             ach = kd["flops"] / kd["launches"] / (per_launch_ms * 1e-3) / 1e12
-            traffic = None
+            traffic, tsrc = None, None
             tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tfile):
                 try:
                     traffic = json.load(open(tfile)).get(dom)
+                    tsrc = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command, committed; " \
+                           "not re-measured in this run)"
                 except Exception:
                     traffic = None
             res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                               "traffic_source": tsrc,
                                "avg_launch_ms": per_launch_ms, "flops_per_launch": kd["flops"] / kd["launches"]}
             res["kernels_per_layer"] = {
                 k: ({"ms": round(v["ms"], 4), "launches": v["launches"],
@@ -219,6 +374,14 @@ def main():
                      "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}) for k, v in ks.items()}
         except Exception as ex:  # the headline number must still be printed
             res["roofline_error"] = repr(ex)
+        del model
+        torch.cuda.empty_cache()
+        extra = res.setdefault("extra", {})
+        for name, leg in (("decode_roofline", lambda: decode_leg(dt)), ("c5", lambda: c5_leg(dt))):
+            try:
+                extra[name] = leg()
+            except Exception as ex:
+                extra[name] = {"error": repr(ex)}
         try:
             r, layers = cpu_baseline(d, H, S)
             res["cpu_baseline"] = {"value": r["tokens_per_s"] * layers / L, "unit": "tokens/s", "cores": r["threads"],
@@ -227,22 +390,37 @@ def main():
                                              f"B=1 S={S} d={d} h={H}, 1 warm-up + 2 timed forwards; value scaled by {layers}/{L} to the full stack"}
         except Exception as ex:
             res["cpu_baseline_error"] = repr(ex)
-
-    if a.parallel_extras and N > 1:
-        extra = {}
         try:
-            from tools.bench_parallel import bench_tp, bench_ring
-            extra["tensor_parallel"] = bench_tp(N, B, S, d, H, I, L, dt, steps=max(2, a.steps // 2))
-            extra["ring_attention"] = bench_ring(N, 65536, d, H, dt, steps=3)
+            res["cpu_baseline_c1"] = cpu_baseline_c1()
         except Exception as ex:
-            extra["error"] = repr(ex)
-        res["extra"] = extra
+            res["cpu_baseline_c1_error"] = repr(ex)
+
+    if N > 1 and not a.no_extra:
+        # BASELINE configs 3 and 4 (strong-scaling measurements of fixed global work; never part of `value`)
+        del model
+        torch.cuda.empty_cache()
+        from tools.bench_parallel import bench_ring, bench_tp
+        extra = res.setdefault("extra", {})
+        legs = [(f"tensor_parallel_tp{tp}", 240, (lambda tp=tp: bench_tp(N, tp, B, S, d, H, I, L, dt, steps=max(2, a.steps // 2))))
+                for tp in (2, 4) if N % tp == 0]
+        legs.append((f"ring_attention_sp{N}", 420, lambda: bench_ring(N, a.ring_seq, d, H, dt, steps=1 if N < 4 else 2)))
+        for name, budget_s, leg in legs:
+            dog.arm(name, budget_s)
+            try:
+                extra[name] = leg()
+            except Exception as ex:
+                extra[name] = {"error": repr(ex)}
+            dog.disarm()
 
     if rank == 0:
         print(json.dumps(res))
+        sys.stdout.flush()
+        dog.printed = True
     if N > 1:
+        dog.arm("shutdown", 60)
         dist.barrier()
         dist.destroy_process_group()
+        dog.disarm()
 
 
 if __name__ == "__main__":

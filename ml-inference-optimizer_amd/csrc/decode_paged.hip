@@ -26,11 +26,15 @@ struct DecDev {
 
 static inline int dec_nsplit(int B, int H, int q_len, int max_ctx) {
   const int64_t rows = (int64_t)B * H * q_len;
-  static const int wgs = [] {  // MIO_DEC_WGS: workgroups the split aims for (tuning aid; default 512 = 2 per CU)
+#ifdef MIO_DIAG
+  static const int wgs = [] {  // MIO_DEC_WGS: workgroups the split aims for (tuning aid)
     const char* e = std::getenv("MIO_DEC_WGS");
     const int v = e ? std::atoi(e) : 0;
     return v > 0 ? v : 512;
   }();
+#else
+  constexpr int wgs = 512;  // workgroups the split aims for: 2 per CU
+#endif
   int want = (int)((wgs + rows - 1) / rows);
   int cap = (max_ctx + 255) / 256;
   if (cap < 1) cap = 1;
@@ -218,20 +222,20 @@ __global__ __launch_bounds__(128) void decode_reduce_kernel(const DecDev p) {
   ((T*)p.o)[b * p.os_b + h * p.os_h + (int64_t)qi * p.os_s + d] = (T)((W > 0.f) ? acc / W : 0.f);
 }
 
-static int dec_unroll() {  // MIO_DEC_U = 1 | 2 | 4 | 8: wave-iterations per batch (tuning aid, read per call; default 2)
-  const char* e = std::getenv("MIO_DEC_U");
-  const int u = e ? std::atoi(e) : 2;
-  return (u == 1 || u == 4 || u == 8) ? u : 2;
-}
-
+// wave-iterations per double-buffered batch: 2 (a sweep of 1 / 2 / 4 / 8 moved the kernel by <= 3 %, 8 slower; the
+// diagnostic build keeps the sweep behind MIO_DEC_U, read once)
 template <typename T, int CPRP>
 static void dec_launch_u(const DecDev& p, dim3 grid, hipStream_t st) {
-  switch (dec_unroll()) {
-    case 1: hipLaunchKernelGGL((decode_paged_kernel<T, CPRP, 1>), grid, dim3(256), 0, st, p); break;
-    case 4: hipLaunchKernelGGL((decode_paged_kernel<T, CPRP, 4>), grid, dim3(256), 0, st, p); break;
-    case 8: hipLaunchKernelGGL((decode_paged_kernel<T, CPRP, 8>), grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((decode_paged_kernel<T, CPRP, 2>), grid, dim3(256), 0, st, p); break;
+#ifdef MIO_DIAG
+  static const int u = [] { const char* e = std::getenv("MIO_DEC_U"); return e ? std::atoi(e) : 2; }();
+  switch (u) {
+    case 1: hipLaunchKernelGGL((decode_paged_kernel<T, CPRP, 1>), grid, dim3(256), 0, st, p); return;
+    case 4: hipLaunchKernelGGL((decode_paged_kernel<T, CPRP, 4>), grid, dim3(256), 0, st, p); return;
+    case 8: hipLaunchKernelGGL((decode_paged_kernel<T, CPRP, 8>), grid, dim3(256), 0, st, p); return;
+    default: break;
   }
+#endif
+  hipLaunchKernelGGL((decode_paged_kernel<T, CPRP, 2>), grid, dim3(256), 0, st, p);
 }
 
 template <typename T>
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(256) void reshape_and_cache_kernel(const uint16_t* 
                                                                 int D, int L, int layer, int bs, int max_blocks) {
   const int b = blockIdx.x;
   const int pos = cl[b] - 1;  // write position (attention_kernels.py:858)
-  if (pos < 0) return;
+  if (pos < 0 || pos / bs >= max_blocks) return;  // empty sequence / context longer than the block table row: nothing written
   const int pb = bt[(int64_t)b * max_blocks + pos / bs];
   const int64_t tok_stride = (int64_t)Hkv * D;
   const int64_t dst = ((int64_t)pb * L + layer) * bs * tok_stride + (int64_t)(pos % bs) * tok_stride;

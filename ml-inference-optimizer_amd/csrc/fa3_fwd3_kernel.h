@@ -40,148 +40,14 @@ struct Fa3Map {
   static constexpr int NU = KU + VU, UPW = (NU + 3) / 4;  // units per stage, per wave
 };
 
+// write one accumulator register a[R] (R >= Fa3Map<D>::A_Q: the asm-owned range; the MFMA statements' clobber lists
+// make the whole file part of the kernel's allocation)
 template <int R>
-struct Fa3AW;  // write one accumulator register (the clobber makes the register part of the kernel's allocation)
-#define FA3_AW(R)                                                                      \
-  template <>                                                                          \
-  struct Fa3AW<R> {                                                                    \
-    static __device__ __forceinline__ void w(uint32_t v) {                             \
-      asm volatile("v_accvgpr_write_b32 a" #R ", %0" : : "v"(v) : "a" #R);             \
-    }                                                                                  \
-  };
-FA3_AW(28)
-FA3_AW(29)
-FA3_AW(30)
-FA3_AW(31)
-FA3_AW(32)
-FA3_AW(33)
-FA3_AW(34)
-FA3_AW(35)
-FA3_AW(36)
-FA3_AW(37)
-FA3_AW(38)
-FA3_AW(39)
-FA3_AW(40)
-FA3_AW(41)
-FA3_AW(42)
-FA3_AW(43)
-FA3_AW(44)
-FA3_AW(45)
-FA3_AW(46)
-FA3_AW(47)
-FA3_AW(48)
-FA3_AW(49)
-FA3_AW(50)
-FA3_AW(51)
-FA3_AW(52)
-FA3_AW(53)
-FA3_AW(54)
-FA3_AW(55)
-FA3_AW(56)
-FA3_AW(57)
-FA3_AW(58)
-FA3_AW(59)
-FA3_AW(60)
-FA3_AW(61)
-FA3_AW(62)
-FA3_AW(63)
-FA3_AW(64)
-FA3_AW(65)
-FA3_AW(66)
-FA3_AW(67)
-FA3_AW(68)
-FA3_AW(69)
-FA3_AW(70)
-FA3_AW(71)
-FA3_AW(72)
-FA3_AW(73)
-FA3_AW(74)
-FA3_AW(75)
-FA3_AW(76)
-FA3_AW(77)
-FA3_AW(78)
-FA3_AW(79)
-FA3_AW(80)
-FA3_AW(81)
-FA3_AW(82)
-FA3_AW(83)
-FA3_AW(84)
-FA3_AW(85)
-FA3_AW(86)
-FA3_AW(87)
-FA3_AW(88)
-FA3_AW(89)
-FA3_AW(90)
-FA3_AW(91)
-FA3_AW(92)
-FA3_AW(93)
-FA3_AW(94)
-FA3_AW(95)
-FA3_AW(96)
-FA3_AW(97)
-FA3_AW(98)
-FA3_AW(99)
-FA3_AW(100)
-FA3_AW(101)
-FA3_AW(102)
-FA3_AW(103)
-FA3_AW(104)
-FA3_AW(105)
-FA3_AW(106)
-FA3_AW(107)
-FA3_AW(108)
-FA3_AW(109)
-FA3_AW(110)
-FA3_AW(111)
-FA3_AW(112)
-FA3_AW(113)
-FA3_AW(114)
-FA3_AW(115)
-FA3_AW(116)
-FA3_AW(117)
-FA3_AW(118)
-FA3_AW(119)
-FA3_AW(120)
-FA3_AW(121)
-FA3_AW(122)
-FA3_AW(123)
-FA3_AW(124)
-FA3_AW(125)
-FA3_AW(126)
-FA3_AW(127)
-FA3_AW(128)
-FA3_AW(129)
-FA3_AW(130)
-FA3_AW(131)
-FA3_AW(132)
-FA3_AW(133)
-FA3_AW(134)
-FA3_AW(135)
-FA3_AW(136)
-FA3_AW(137)
-FA3_AW(138)
-FA3_AW(139)
-FA3_AW(140)
-FA3_AW(141)
-FA3_AW(142)
-FA3_AW(143)
-FA3_AW(144)
-FA3_AW(145)
-FA3_AW(146)
-FA3_AW(147)
-FA3_AW(148)
-FA3_AW(149)
-FA3_AW(150)
-FA3_AW(151)
-FA3_AW(152)
-FA3_AW(153)
-FA3_AW(154)
-FA3_AW(155)
-FA3_AW(156)
-FA3_AW(157)
-FA3_AW(158)
-FA3_AW(159)
-#undef FA3_AW
+struct Fa3AW {
+  static __device__ __forceinline__ void w(uint32_t v) {
+    asm volatile("v_accvgpr_write_b32 a[%1], %0" : : "v"(v), "n"(R));
+  }
+};
 
 template <typename T>
 struct Fa3Ops;

@@ -1,5 +1,8 @@
 // One translation unit per (dtype, padded head dim): compiled with -DFA_TYPE_ID={0,1} -DFA_D={64,96,128}.
+// The product library reads no environment variable and keeps no unsynchronised mutable state; the A/B switches and the
+// in-kernel stamp instantiations exist only in the diagnostic build (make dbg: -DMIO_DIAG -> libmio_hip_dbg.so).
 #include <cstdlib>
+#include <mutex>
 
 #include "fa3_fwd2_kernel.h"
 #include "fa3_fwd3_kernel.h"
@@ -15,11 +18,11 @@ static int launch_one(const FaDev& p, hipStream_t stream) {
   const int grid = p.nqblk * p.B * p.H;
   const size_t smem = FaSmem<FA_D>::TOTAL;
   auto kern = fa3_fwd_kernel<FaT, FA_D, CAUSAL, MASK>;
-  static bool attr_set = false;  // > 64 KiB dynamic LDS (D = 128) needs the opt-in once per kernel
-  if (!attr_set && smem > 48 * 1024) {
-    hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 48 * 1024) {  // > 64 KiB dynamic LDS (D = 128) needs the opt-in once per kernel
+    static std::once_flag once;
+    static hipError_t ea = hipSuccess;
+    std::call_once(once, [&] { ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
     if (ea != hipSuccess) return mio_fail(std::string("fa3_fwd: hipFuncSetAttribute: ") + hipGetErrorString(ea));
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, p);
   hipError_t e = hipGetLastError();
@@ -27,27 +30,30 @@ static int launch_one(const FaDev& p, hipStream_t stream) {
   return 0;
 }
 
+#ifdef MIO_DIAG
 // second structure (one wave per SIMD, 64 query rows per wave): no user mask, D % 32 == 0 instantiations
 template <bool CAUSAL>
 static int launch_two(FaDev p, hipStream_t stream) {
   p.nqblk = (p.Sq + FA2_BM - 1) / FA2_BM;
   // causal: a workgroup takes query blocks i and nqblk-1-i back to back -> every workgroup does the same work
   p.qgrid = CAUSAL ? (p.nqblk + 1) / 2 : p.nqblk;
-  if (const char* e = std::getenv("MIO_FA_ORDER")) p.xcd_remap |= std::atoi(e);  // tuning aid: 2 = light-first, 4 = block-major
+  static const int order = [] { const char* e = std::getenv("MIO_FA_ORDER"); return e ? std::atoi(e) : 0; }();
+  p.xcd_remap |= order;  // tuning aid: 2 = light-first, 4 = block-major
   const int grid = p.qgrid * p.B * p.H;
   const size_t smem = FaSmem<FA_D>::TOTAL;
   auto kern = fa3_fwd2_kernel<FaT, FA_D, CAUSAL>;
-  static bool attr_set = false;
-  if (!attr_set && smem > 48 * 1024) {
-    hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 48 * 1024) {
+    static std::once_flag once;
+    static hipError_t ea = hipSuccess;
+    std::call_once(once, [&] { ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
     if (ea != hipSuccess) return mio_fail(std::string("fa3_fwd2: hipFuncSetAttribute: ") + hipGetErrorString(ea));
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mio_fail(std::string("fa3_fwd2 launch: ") + hipGetErrorString(e));
   return 0;
 }
+#endif
 
 // third structure (software-pipelined across KV tiles): no user mask
 template <bool CAUSAL>
@@ -57,15 +63,24 @@ static int launch_three(FaDev p, hipStream_t stream) {
   const int grid = p.qgrid * p.B * p.H;
   const size_t smem = FA3_STAGES * FaSmem<FA_D>::STAGE;
   auto kern = fa3_fwd3_kernel<FaT, FA_D, CAUSAL>;
-  if (const char* e = std::getenv("MIO_FA_DBG_PTR")) {  // diagnostic build with in-kernel phase stamps (tools/fa_stamps.py)
-    kern = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, true>;
-    p.mask = (const void*)std::strtoull(e, nullptr, 0);
+#ifdef MIO_DIAG
+  static const char* dbg_ptr = std::getenv("MIO_FA_DBG_PTR");  // in-kernel phase stamps (tools/fa_stamps.py)
+  if (dbg_ptr != nullptr) {
+    auto kd = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, true>;
+    p.mask = (const void*)std::strtoull(dbg_ptr, nullptr, 0);
+    hipError_t ed = hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (ed != hipSuccess) return mio_fail(std::string("fa3_fwd3 (stamps): hipFuncSetAttribute: ") + hipGetErrorString(ed));
+    hipLaunchKernelGGL(kd, dim3(grid), dim3(256), smem, stream, p);
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) return mio_fail(std::string("fa3_fwd3 (stamps) launch: ") + hipGetErrorString(e2));
+    return 0;
   }
-  static bool attr_set = false;
-  if (!attr_set || std::getenv("MIO_FA_DBG_PTR")) {
-    hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+  {
+    static std::once_flag once;
+    static hipError_t ea = hipSuccess;
+    std::call_once(once, [&] { ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
     if (ea != hipSuccess) return mio_fail(std::string("fa3_fwd3: hipFuncSetAttribute: ") + hipGetErrorString(ea));
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, p);
   hipError_t e = hipGetLastError();
@@ -73,6 +88,7 @@ static int launch_three(FaDev p, hipStream_t stream) {
   return 0;
 }
 
+#ifdef MIO_DIAG
 static int fa_impl() {  // MIO_FA_IMPL=1 / 2 / 3 force one structure for A/B runs (0 = the rule in fa3_launch)
   static const int v = [] {
     const char* e = std::getenv("MIO_FA_IMPL");
@@ -80,6 +96,9 @@ static int fa_impl() {  // MIO_FA_IMPL=1 / 2 / 3 force one structure for A/B run
   }();
   return v;
 }
+#else
+static constexpr int fa_impl() { return 0; }
+#endif
 
 template <>
 int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t stream) {
@@ -92,9 +111,10 @@ int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t
   const bool span32 = (int64_t)p.Sk * p.ks_s * 2 < (1ll << 32) && (int64_t)p.Sk * p.vs_s * 2 < (1ll << 32);
   if ((fa_impl() == 3 || fa_impl() == 0) && mask_kind == MIO_MASK_NONE && p.Sq > 128 && span32)
     return causal ? launch_three<true>(p, stream) : launch_three<false>(p, stream);
-  const bool two = (fa_impl() == 2);
-  if (mask_kind == MIO_MASK_NONE && two && p.Sq > 128)
+#ifdef MIO_DIAG
+  if (mask_kind == MIO_MASK_NONE && fa_impl() == 2 && p.Sq > 128)
     return causal ? launch_two<true>(p, stream) : launch_two<false>(p, stream);
+#endif
   if (causal) {
     if (mask_kind == MIO_MASK_NONE) return launch_one<true, 0>(p, stream);
     if (mask_kind == MIO_MASK_KEEP_U8) return launch_one<true, 1>(p, stream);

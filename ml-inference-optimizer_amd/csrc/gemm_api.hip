@@ -7,21 +7,23 @@
 extern template int gemm_launch<__bf16>(GemmDev, int, hipStream_t);
 extern template int gemm_launch<_Float16>(GemmDev, int, hipStream_t);
 
-// MIO_GEMM_IMPL=v1|8p|4w|2x|4wp|4w16 selects an older pipeline for A/B comparisons (read once); 0 = default dispatch.
+// Diagnostic build only: MIO_GEMM_IMPL=v1|4wp|4w16 forces one pipeline for A/B comparisons (read once).  The product
+// library always takes the default dispatch (0) and reads no environment variable.
 int mio_gemm_impl() {
+#ifdef MIO_DIAG
   static const int v = [] {
     const char* e = std::getenv("MIO_GEMM_IMPL");
     if (e == nullptr) return 0;
     const std::string s(e);
     if (s == "v1") return 1;
-    if (s == "8p") return 2;
-    if (s == "4w") return 3;
-    if (s == "2x") return 4;
     if (s == "4wp") return 5;
     if (s == "4w16") return 6;
     return 0;
   }();
   return v;
+#else
+  return 0;
+#endif
 }
 
 static int gemm_dispatch(const GemmDev& p, int act, int dtype, hipStream_t st) {

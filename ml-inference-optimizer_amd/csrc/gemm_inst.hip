@@ -1,12 +1,10 @@
 // One translation unit per dtype: compiled with -DGEMM_TYPE_ID={0,1}.
-#include <cstdio>
+// The product library reads no environment variable; A/B switches and stamp instantiations: -DMIO_DIAG (make dbg).
 #include <cstdlib>
+#include <mutex>
 
-#include "gemm2x_kernel.h"
 #include "gemm4w16_kernel.h"
 #include "gemm4w16p_kernel.h"
-#include "gemm4w_kernel.h"
-#include "gemm8p_kernel.h"
 
 #if GEMM_TYPE_ID == 0
 using GT = __bf16;
@@ -21,82 +19,29 @@ static int launch_cfg(GemmDev p, hipStream_t stream) {
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (p.N + BN - 1) / BN;
   auto kern = gemm_bias_act_kernel<GT, BM, BN, WM, WN, ACT>;
-  static bool attr_set = false;  // > 64 KiB dynamic LDS needs the opt-in once per kernel
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return mio_fail(std::string("gemm: hipFuncSetAttribute: ") + hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::once_flag once;  // > 64 KiB dynamic LDS needs the opt-in once per kernel
+  static hipError_t ea = hipSuccess;
+  std::call_once(once, [&] { ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+  if (ea != hipSuccess) return mio_fail(std::string("gemm: hipFuncSetAttribute: ") + hipGetErrorString(ea));
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), smem, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mio_fail(std::string("gemm launch: ") + hipGetErrorString(e));
   return 0;
 }
 
-static int gemm_var() {  // MIO_GEMM_VAR=<bits>: timing-only ablations of the ACT_NONE 8-phase kernel (tuning aid)
+#ifdef MIO_DIAG
+static int gemm_var() {  // MIO_GEMM_VAR=<bits>: timing-only ablations of the ACT_NONE one-tile kernel (tuning aid)
   static const int v = [] {
     const char* e = std::getenv("MIO_GEMM_VAR");
     return e ? std::atoi(e) : 0;
   }();
   return v;
 }
+#endif
 
-template <int ACT, int VAR = 0>
-static int launch_8p(GemmDev p, hipStream_t stream) {
-  if constexpr (ACT == MIO_ACT_NONE && VAR == 0) {
-    switch (gemm_var()) {
-      case 1: return launch_8p<ACT, 1>(p, stream);
-      case 2: return launch_8p<ACT, 2>(p, stream);
-      case 4: return launch_8p<ACT, 4>(p, stream);
-      case 8: return launch_8p<ACT, 8>(p, stream);
-      case 12: return launch_8p<ACT, 12>(p, stream);
-      default: break;
-    }
-  }
-  p.tiles_m = (int)((p.M + 255) / 256);
-  p.tiles_n = (p.N + 255) / 256;
-  auto kern = gemm8p_kernel<GT, ACT, VAR>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G8_SMEM);
-    if (e != hipSuccess) return mio_fail(std::string("gemm8p: hipFuncSetAttribute: ") + hipGetErrorString(e));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), G8_SMEM, stream, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return mio_fail(std::string("gemm8p launch: ") + hipGetErrorString(e));
-  return 0;
-}
-
-static int gemm_var();
-template <int ACT, int VAR = 0>
-static int launch_4w(GemmDev p, hipStream_t stream) {
-  if constexpr (ACT == MIO_ACT_NONE && VAR == 0) {
-    switch (gemm_var()) {
-      case 4: return launch_4w<ACT, 4>(p, stream);
-      case 8: return launch_4w<ACT, 8>(p, stream);
-      case 12: return launch_4w<ACT, 12>(p, stream);
-      default: break;
-    }
-  }
-  p.tiles_m = (int)((p.M + 255) / 256);
-  p.tiles_n = (p.N + 255) / 256;
-  auto kern = gemm4w_kernel<GT, ACT, VAR>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G4_SMEM);
-    if (e != hipSuccess) return mio_fail(std::string("gemm4w: hipFuncSetAttribute: ") + hipGetErrorString(e));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), G4_SMEM, stream, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return mio_fail(std::string("gemm4w launch: ") + hipGetErrorString(e));
-  return 0;
-}
-
-static int gemm_var();
 template <int ACT, int VAR = 0>
 static int launch_4w16(GemmDev p, hipStream_t stream) {
+#ifdef MIO_DIAG
   if constexpr (ACT == MIO_ACT_NONE && VAR == 0) {
     if (p.dbg != nullptr) {
       switch (gemm_var()) {
@@ -110,15 +55,14 @@ static int launch_4w16(GemmDev p, hipStream_t stream) {
     }
     if (gemm_var() == 16) return launch_4w16<ACT, 16>(p, stream);
   }
+#endif
   p.tiles_m = (int)((p.M + 255) / 256);
   p.tiles_n = (p.N + 255) / 256;
   auto kern = gemm4w16_kernel<GT, ACT, VAR>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G6_SMEM);
-    if (e != hipSuccess) return mio_fail(std::string("gemm4w16: hipFuncSetAttribute: ") + hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::once_flag once;
+  static hipError_t ea = hipSuccess;
+  std::call_once(once, [&] { ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G6_SMEM); });
+  if (ea != hipSuccess) return mio_fail(std::string("gemm4w16: hipFuncSetAttribute: ") + hipGetErrorString(ea));
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), G6_SMEM, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mio_fail(std::string("gemm4w16 launch: ") + hipGetErrorString(e));
@@ -136,43 +80,35 @@ static int launch_4w16p(GemmDev p, hipStream_t stream) {
   }
   p.tiles_m = (int)((p.M + 255) / 256);
   p.tiles_n = (p.N + 255) / 256;
-  constexpr bool CAN_STAMP = (ACT == MIO_ACT_NONE && SPK == 1);
   auto kern = gemm4w16p_kernel<GT, ACT, (SPK == 0 ? 1 : SPK)>;
-  if constexpr (CAN_STAMP) {
-    if (p.dbg != nullptr) kern = gemm4w16p_kernel<GT, ACT, 1, true>;
-  }
-  static bool attr_set = false;
+  static std::once_flag once;
+  static hipError_t ea = hipSuccess;
   static int ncu = 256;
-  if (!attr_set || p.dbg != nullptr) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G6P_SMEM);
-    if (e != hipSuccess) return mio_fail(std::string("gemm4w16p: hipFuncSetAttribute: ") + hipGetErrorString(e));
+  std::call_once(once, [&] {
+    ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G6P_SMEM);
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
       ncu = n & ~7;  // whole XCD groups, so tile % 8 keeps naming the XCD
-    attr_set = true;
-  }
+  });
+  if (ea != hipSuccess) return mio_fail(std::string("gemm4w16p: hipFuncSetAttribute: ") + hipGetErrorString(ea));
   const int tiles = p.tiles_m * p.tiles_n;
+#ifdef MIO_DIAG
+  if constexpr (ACT == MIO_ACT_NONE && SPK == 1) {
+    if (p.dbg != nullptr) {  // in-kernel stamps (tools/gemm_stamps_p.py)
+      auto kd = gemm4w16p_kernel<GT, ACT, 1, true>;
+      hipError_t ed = hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, G6P_SMEM);
+      if (ed != hipSuccess) return mio_fail(std::string("gemm4w16p (stamps): hipFuncSetAttribute: ") + hipGetErrorString(ed));
+      hipLaunchKernelGGL(kd, dim3(tiles < ncu ? tiles : ncu), dim3(256), G6P_SMEM, stream, p);
+      hipError_t e2 = hipGetLastError();
+      if (e2 != hipSuccess) return mio_fail(std::string("gemm4w16p (stamps) launch: ") + hipGetErrorString(e2));
+      return 0;
+    }
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3(tiles < ncu ? tiles : ncu), dim3(256), G6P_SMEM, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mio_fail(std::string("gemm4w16p launch: ") + hipGetErrorString(e));
-  return 0;
-}
-
-template <int ACT>
-static int launch_2x(GemmDev p, hipStream_t stream) {
-  p.tiles_m = (int)((p.M + 255) / 256);
-  p.tiles_n = (p.N + 127) / 128;
-  auto kern = gemm2x_kernel<GT, ACT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
-    if (e != hipSuccess) return mio_fail(std::string("gemm2x: hipFuncSetAttribute: ") + hipGetErrorString(e));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), G2_SMEM, stream, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return mio_fail(std::string("gemm2x launch: ") + hipGetErrorString(e));
   return 0;
 }
 
@@ -190,12 +126,9 @@ static int launch_act(const GemmDev& p, hipStream_t stream) {
     const int64_t big = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (big >= 256) {
       if (gemm_impl() == 1) return launch_cfg<256, 256, 2, 4, ACT>(p, stream);
-      if (gemm_impl() == 2) return launch_8p<ACT>(p, stream);
-      if (gemm_impl() == 3) return launch_4w<ACT>(p, stream);
       // the 16x16x32 kernel addresses operands with 32-bit per-tile byte offsets and needs whole K-tiles
       const bool fits = (p.K % 32 == 0) && (p.ldx * 512 < (int64_t)0x7fffffff) && (p.ldw * 512 < (int64_t)0x7fffffff);
       if (!fits) return launch_cfg<256, 256, 2, 4, ACT>(p, stream);
-      if (gemm_impl() == 4) return launch_2x<ACT>(p, stream);
       // no residual: persistent kernel with the overlapped epilogue (MIO_GEMM_IMPL=4w16 keeps the one-tile kernel)
       if (gemm_impl() != 6 && p.res == nullptr && p.K >= 256 && p.K % 64 == 0 && p.ldy * 512 < (int64_t)0x7fffffff)
         return launch_4w16p<ACT>(p, stream);
@@ -207,11 +140,10 @@ static int launch_act(const GemmDev& p, hipStream_t stream) {
 
 template <>
 int gemm_launch<GT>(GemmDev p, int act, hipStream_t stream) {
-  if (const char* e = std::getenv("MIO_GEMM_DBG_PTR")) {
-    p.dbg = (unsigned long long*)std::strtoull(e, nullptr, 0);
-    static int once = 0;
-    if (!once++) fprintf(stderr, "[mio] gemm stamps -> %p (act %d)\n", (void*)p.dbg, act);
-  }
+#ifdef MIO_DIAG
+  static const char* dbg_ptr = std::getenv("MIO_GEMM_DBG_PTR");
+  if (dbg_ptr != nullptr) p.dbg = (unsigned long long*)std::strtoull(dbg_ptr, nullptr, 0);
+#endif
   switch (act) {
     case MIO_ACT_NONE: return launch_act<MIO_ACT_NONE>(p, stream);
     case MIO_ACT_GELU_TANH: return launch_act<MIO_ACT_GELU_TANH>(p, stream);

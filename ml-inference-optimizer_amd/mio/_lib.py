@@ -15,7 +15,9 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmio_hip.so")
+# MIO_LIB_DBG=1 (tools/ only): the diagnostic build (`make dbg`), which carries the A/B switches and the in-kernel
+# stamp instantiations; the product library reads no environment variable and has neither.
+LIB_PATH = os.path.join(_HERE, "libmio_hip_dbg.so" if os.environ.get("MIO_LIB_DBG") == "1" else "libmio_hip.so")
 
 MIO_BF16, MIO_FP16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_RELU, ACT_SILU, ACT_SWIGLU = range(6)

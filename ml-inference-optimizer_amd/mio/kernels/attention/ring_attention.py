@@ -141,8 +141,9 @@ class RingCrossAttention(RingAttention):
         self.attention_dropout = nn.Dropout(config.attention_dropout)
 
     def forward(self, query_states: torch.Tensor, key_value_states: torch.Tensor,
-                attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """query_states [B,Sq,d], key_value_states [B,Sk,d], additive mask [B,1|H,Sq,Sk] (:442-499)."""
+                attention_mask: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """query_states [B,Sq,d], key_value_states [B,Sk,d], additive mask [B,1|H,Sq,Sk] (:442-499).
+        residual (not in the reference): added in the out-projection's epilogue."""
         in_dtype = query_states.dtype
         dt = self._check(query_states)
         self._check(key_value_states)
@@ -153,5 +154,6 @@ class RingCrossAttention(RingAttention):
         k = self._heads(linear(xkv, self.k_proj, c, dt))
         v = self._heads(linear(xkv, self.v_proj, c, dt))
         ctx = ops.ring_attention_forward(q, k, v, attention_mask)
-        out = linear(ctx, self.out_proj, c, dt)
+        r = None if residual is None else (residual if residual.dtype == dt else residual.to(dt))
+        out = linear(ctx, self.out_proj, c, dt, residual=r)
         return out if out.dtype == in_dtype else out.to(in_dtype)

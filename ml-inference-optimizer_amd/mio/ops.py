@@ -58,6 +58,30 @@ def _need_cuda(*ts: Optional[torch.Tensor]) -> None:
             raise ValueError("HIP kernels require input tensors to be on a CUDA (ROCm) device.")
 
 
+def _vec_ok(t: Optional[torch.Tensor], n: int, dtype: torch.dtype, what: str) -> None:
+    """A per-column operand (bias, LayerNorm weight): 1-D, contiguous, n elements, the activations' dtype and device.
+    The kernels read n elements of the activation dtype from the raw pointer, so anything else would be misread."""
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise ValueError("HIP kernels require input tensors to be on a CUDA (ROCm) device.")
+    if t.dim() != 1 or t.numel() != n or not t.is_contiguous():
+        raise ValueError(f"{what} must be a contiguous 1-D tensor of {n} elements, got shape {tuple(t.shape)}")
+    if t.dtype != dtype:
+        raise ValueError(f"{what} must have the activation dtype {dtype}, got {t.dtype}")
+
+
+def _res_ok(r: Optional[torch.Tensor], numel: int, dtype: torch.dtype) -> None:
+    if r is None:
+        return
+    if not r.is_cuda:
+        raise ValueError("HIP kernels require input tensors to be on a CUDA (ROCm) device.")
+    if r.dtype != dtype:
+        raise ValueError(f"residual must have the activation dtype {dtype}, got {r.dtype}")
+    if r.numel() != numel:
+        raise ValueError(f"residual has {r.numel()} elements, the output has {numel}")
+
+
 def _rows16(t: torch.Tensor) -> torch.Tensor:
     """Make the last dim contiguous and every other stride a multiple of 8 elements."""
     if t.stride(-1) != 1 or any(s % 8 for s in t.stride()[:-1]) or t.data_ptr() % 16:
@@ -292,6 +316,9 @@ def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_g
     N = w.shape[0]
     if w.shape[1] != K:
         raise ValueError(f"weight shape {tuple(w.shape)} does not match input features {K}")
+    _vec_ok(bias, N, x.dtype, "bias")
+    if act == _lib.ACT_SWIGLU:
+        _vec_ok(bias_gate, N, x.dtype, "bias_gate")
     if x_blocked_shape is not None:
         # x is layernorm(..., out_blocked=True) of a tensor of shape x_blocked_shape: blocked activation layout
         M = int(math.prod(x_blocked_shape[:-1]))
@@ -300,6 +327,7 @@ def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_g
         if out is None:
             out = torch.empty(*x_blocked_shape[:-1], N, dtype=x.dtype, device=x.device)
         y2 = out.view(-1, N)
+        _res_ok(residual, M * N, x.dtype)
         r2 = None if residual is None else _rows16(residual.reshape(-1, N))
         check(lib.mio_gemm_bias_act_bw(x.data_ptr(), w_blocked.data_ptr(), _ptr(bias), _ptr(r2), y2.data_ptr(), M, N, K,
                                        K, y2.stride(0), 0 if r2 is None else r2.stride(0), act, dt, 1, _stream()))
@@ -318,10 +346,8 @@ def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_g
     y2 = out.view(-1, N)
     r2 = None
     if residual is not None:
+        _res_ok(residual, M * N, x.dtype)
         r2 = _rows16(residual.reshape(-1, N))
-    for b_ in (bias, bias_gate):
-        if b_ is not None and (b_.dtype != x.dtype or not b_.is_contiguous()):
-            raise ValueError("bias must be contiguous and of the input dtype")
     if w_blocked is not None and act != _lib.ACT_SWIGLU and lib.mio_gemm_blocked_weight_ok(M, N, K, act) and \
             x2.stride(0) * 512 < 0x7fffffff:
         check(lib.mio_gemm_bias_act_bw(x2.data_ptr(), w_blocked.data_ptr(), _ptr(bias), _ptr(r2), y2.data_ptr(), M, N, K,
@@ -359,6 +385,9 @@ def fused_mlp(
         # hidden_states is layernorm(..., out_blocked=True) of a [B,S,d] tensor: blocked activation layout
         d, I = x_blocked_shape[-1], fc1_weight.shape[0]
         M = int(math.prod(x_blocked_shape[:-1]))
+        _vec_ok(fc1_bias, I, hidden_states.dtype, "fc1_bias")
+        _vec_ok(fc2_bias, d, hidden_states.dtype, "fc2_bias")
+        _res_ok(residual, M * d, hidden_states.dtype)
         if fc1_blocked is None or fc2_blocked is None or not lib.mio_fused_mlp_blocked_weight_ok(M, d, I, act):
             raise ValueError("a blocked activation operand needs blocked weights and fused_mlp_blocked_weight_ok()")
         out = torch.empty(*x_blocked_shape, dtype=hidden_states.dtype, device=hidden_states.device)
@@ -381,6 +410,11 @@ def fused_mlp(
     if x2.stride(0) != d:
         x2 = x2.contiguous()
     M = x2.shape[0]
+    _vec_ok(fc1_bias, I, hidden_states.dtype, "fc1_bias")
+    _vec_ok(fc2_bias, d, hidden_states.dtype, "fc2_bias")
+    if act == _lib.ACT_SWIGLU:
+        _vec_ok(fc1_gate_bias, I, hidden_states.dtype, "fc1_gate_bias")
+    _res_ok(residual, M * d, hidden_states.dtype)
     ws = [fc1_weight, fc2_weight] + ([fc1_gate_weight] if act == _lib.ACT_SWIGLU else [])
     for w_ in ws:
         if w_.dtype != hidden_states.dtype or not w_.is_contiguous():
@@ -414,6 +448,9 @@ def layernorm(x, weight, bias=None, eps: float = 1e-5, residual=None, residual_a
     _need_cuda(x, weight)
     dt = _dtype_id(x)
     cols = x.shape[-1]
+    _vec_ok(weight, cols, x.dtype, "layernorm weight")
+    _vec_ok(bias, cols, x.dtype, "layernorm bias")
+    _res_ok(residual, x.numel(), x.dtype)
     x2 = x.reshape(-1, cols)
     if not x2.is_contiguous():
         x2 = x2.contiguous()

@@ -88,24 +88,48 @@ def all_reduce(tensor: torch.Tensor, op: Union[dist.ReduceOp, str] = dist.Reduce
         if avg:
             tensor.div_(get_world_size(group))
 
-    if stream is not None and tensor.is_cuda:
-        stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(stream):
+    side = stream if (stream is not None and tensor.is_cuda) else None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
             work = dist.all_reduce(comm, op=rop, group=group, async_op=async_op)
             if not async_op:
                 _finish()
         if not async_op:
-            torch.cuda.current_stream().wait_stream(stream)
+            torch.cuda.current_stream().wait_stream(side)
             return tensor
-        return work, tensor
+        return _AsyncReduce(work, _finish, side), tensor
     work = dist.all_reduce(comm, op=rop, group=group, async_op=async_op)
     if async_op:
-        if comm is not tensor or avg:
-            work.wait()
-            _finish()
-        return work, tensor
+        return _AsyncReduce(work, _finish, None), tensor
     _finish()
     return tensor
+
+
+class _AsyncReduce:
+    """Handle of an asynchronous all_reduce: wait() = the collective is ordered before what the caller launches next
+    AND the post-processing (copy back from the wire dtype, the division of "avg") has run -- on the side stream when
+    one was given.  (A bare `work` would hand the caller an un-averaged / un-copied tensor.)"""
+
+    def __init__(self, work, finish, stream):
+        self._work, self._finish, self._stream, self._done = work, finish, stream, False
+
+    def wait(self):
+        if self._done:
+            return True
+        if self._stream is not None:
+            with torch.cuda.stream(self._stream):
+                self._work.wait()
+                self._finish()
+            torch.cuda.current_stream().wait_stream(self._stream)
+        else:
+            self._work.wait()
+            self._finish()
+        self._done = True
+        return True
+
+    def is_completed(self):
+        return self._done or self._work.is_completed()
 
 
 def all_gather(tensor: torch.Tensor, dim: int = 0, async_op: bool = False,
@@ -170,35 +194,67 @@ def barrier(group: Optional[dist.ProcessGroup] = None) -> None:
         dist.barrier(group=group)
 
 
-def _contiguous_groups(world_size: int, size: int, tag: str) -> Optional[dist.ProcessGroup]:
-    """Contiguous rank blocks of `size` (reference :493-498, :607-619); every rank creates every group
-    (new_group is collective) and keeps its own.  Cached so repeated module construction is free."""
+def _strided_groups(world_size: int, size: int, stride: int, tag: str) -> Optional[dist.ProcessGroup]:
+    """Groups {base + i * stride, i < size} covering all ranks (stride 1 = the reference's contiguous rank blocks,
+    :493-498, :607-619); every rank creates every group (new_group is collective) and keeps its own.  Cached so
+    repeated module construction is free."""
     if not dist.is_initialized():
         raise RuntimeError("Distributed environment not initialized. Call initialize_distributed first.")
-    if world_size % size != 0:
-        raise ValueError(f"group size ({size}) must divide world size ({world_size})")
-    key = (tag, world_size, size)
+    if world_size % (size * stride) != 0:
+        raise ValueError(f"group size ({size}) x stride ({stride}) must divide world size ({world_size})")
+    key = (tag, world_size, size, stride)
     if key in _GROUP_CACHE:
         return _GROUP_CACHE[key]
     rank = dist.get_rank()
     mine = None
-    for g in range(world_size // size):
-        ranks = list(range(g * size, (g + 1) * size))
-        grp = dist.new_group(ranks)
-        if rank in ranks:
-            mine = grp
+    for outer in range(world_size // (size * stride)):
+        for inner in range(stride):
+            ranks = [outer * size * stride + inner + i * stride for i in range(size)]
+            grp = dist.new_group(ranks)
+            if rank in ranks:
+                mine = grp
     _GROUP_CACHE[key] = mine
     return mine
 
 
+def _registered(kind: str):
+    """(True, group) when parallel_utils.initialize_parallel_groups has registered the data x sequence x tensor mesh."""
+    from . import parallel_utils
+    if parallel_utils._PARALLEL_GROUPS:
+        return True, parallel_utils._PARALLEL_GROUPS.get(kind)
+    return False, None
+
+
 def setup_device_groups(world_size: int, tp_size: int) -> Optional[dist.ProcessGroup]:
-    """Tensor-parallel group of this rank (reference :464-500)."""
-    return _contiguous_groups(world_size, tp_size, "tp")
+    """Tensor-parallel group of this rank (reference :464-500): the registered mesh group when
+    initialize_parallel_groups was called, else adjacent ranks (the mesh's innermost dimension)."""
+    reg, grp = _registered("tensor")
+    if reg:
+        if (1 if grp is None else dist.get_world_size(grp)) != tp_size:
+            raise ValueError(f"tp_size {tp_size} does not match the registered tensor-parallel group")
+        return grp
+    if tp_size > 1 and any(k[0] == "sp" and k[2] > 1 and k[3] != tp_size for k in _GROUP_CACHE):
+        raise RuntimeError("tensor-parallel groups of adjacent ranks would share ranks with the sequence-parallel groups "
+                           "already built: call parallel_utils.initialize_parallel_groups(ParallelConfig(...)) first, or "
+                           "give SequenceParallelConfig the tp_size")
+    return _strided_groups(world_size, tp_size, 1, "tp")
 
 
-def setup_sequence_parallel_group(world_size: int, sp_size: int) -> Optional[dist.ProcessGroup]:
-    """Sequence-parallel group of this rank (reference :580-619)."""
-    return _contiguous_groups(world_size, sp_size, "sp")
+def setup_sequence_parallel_group(world_size: int, sp_size: int, tp_size: int = 1) -> Optional[dist.ProcessGroup]:
+    """Sequence-parallel group of this rank (reference :580-619).  With tensor parallelism in the same job the
+    sequence dimension strides by tp_size (mesh rank = (dp * SP + sp) * TP + tp): the reference builds both kinds from
+    contiguous blocks, which makes a tp x sp job exchange K/V between ranks that hold different heads of the SAME
+    tokens.  Resolution order: the mesh registered by initialize_parallel_groups; else stride tp_size."""
+    reg, grp = _registered("sequence")
+    if reg:
+        if (1 if grp is None else dist.get_world_size(grp)) != sp_size:
+            raise ValueError(f"sp_size {sp_size} does not match the registered sequence-parallel group")
+        return grp
+    if sp_size > 1 and tp_size == 1 and any(k[0] == "tp" and k[2] > 1 for k in _GROUP_CACHE):
+        raise RuntimeError("sequence-parallel groups of contiguous ranks would share ranks with the tensor-parallel groups "
+                           "already built: call parallel_utils.initialize_parallel_groups(ParallelConfig(...)) first, or "
+                           "give SequenceParallelConfig the tp_size")
+    return _strided_groups(world_size, sp_size, tp_size, "sp")
 
 
 def scatter_along_sequence_dim(tensor: torch.Tensor, sp_size: Optional[int] = None,
@@ -270,17 +326,34 @@ def ring_exchange(*tensors: torch.Tensor, group: Optional[dist.ProcessGroup] = N
     return out
 
 
-def mesh_exchange_start(tensors: Sequence[torch.Tensor], group: Optional[dist.ProcessGroup] = None):
+def mesh_exchange_start(tensors: Sequence[torch.Tensor], group: Optional[dist.ProcessGroup] = None,
+                        buffers: Optional[dict] = None):
     """Full-mesh variant of the ring pass for an 8-GPU xGMI node: rank r sends its tensors to EVERY
     peer and receives every peer's tensors, all posted in one grouped call so each of the 7 links
     carries one transfer concurrently (a neighbour ring would use 1 of the 7 links, hop by hop).
     Returns (handle, chunks) where chunks[i] is the list of tensors that originated on rank (r - i) % ws
-    (chunks[0] = the local tensors), i.e. the same order a ring pass would deliver them in."""
+    (chunks[0] = the local tensors), i.e. the same order a ring pass would deliver them in.
+
+    handle.wait_chunk(i) orders chunk i's arrival before what the caller launches next.  Backends that return one
+    work per transfer (gloo) wait per origin; RCCL coalesces a grouped call into ONE work, so the first wait_chunk
+    covers every peer -- deliberately: per-origin completion on RCCL would need one group call per peer, and those run
+    one after the other on the communicator's stream, i.e. one link at a time (7 x the transfer time of the one-group
+    form, which already lands every chunk in about the time the local chunk's attention takes).
+
+    buffers: a dict the caller keeps between calls (SequenceParallelConfig.buffer_reuse): the ws - 1 receive buffers
+    are allocated once per (shape, dtype, device) instead of once per call."""
     ws = get_world_size(group)
     local = [t.contiguous() for t in tensors]
     if not dist.is_initialized() or ws == 1:
         return None, [local]
     r = get_rank(group)
+    key = tuple((tuple(t.shape), t.dtype, str(t.device)) for t in local) + (ws,)
+    pool = None if buffers is None else buffers.get(key)
+    if pool is None:
+        pool = [[torch.empty_like(t) for t in local] for _ in range(ws - 1)]
+        if buffers is not None:
+            buffers.clear()  # one live shape per module: a new shape replaces the old pool
+            buffers[key] = pool
     chunks: List[List[torch.Tensor]] = [local]
     ops_ = []
     for i in range(1, ws):
@@ -288,16 +361,38 @@ def mesh_exchange_start(tensors: Sequence[torch.Tensor], group: Optional[dist.Pr
         dst = (r + i) % ws
         gsrc = dist.get_global_rank(group, src) if group is not None else src
         gdst = dist.get_global_rank(group, dst) if group is not None else dst
-        bufs = [torch.empty_like(t) for t in local]
+        bufs = pool[i - 1]
         chunks.append(bufs)
         for t, b in zip(local, bufs):
             ops_.append(dist.P2POp(dist.isend, t, gdst, group))
             ops_.append(dist.P2POp(dist.irecv, b, gsrc, group))
     works = dist.batch_isend_irecv(ops_)
+    per_op = len(works) == len(ops_)
+    n_t = 2 * len(local)  # works per origin
 
     class _Handle:
+        def __init__(self_inner):
+            self_inner._waited = set()
+
+        def wait_chunk(self_inner, i: int):
+            """Chunk i (origin (r - i) % ws) has arrived -- and, per-op backends, our send paired with it was posted."""
+            if i <= 0 or i in self_inner._waited:
+                return
+            if per_op:
+                for w in works[(i - 1) * n_t:i * n_t]:
+                    w.wait()
+                self_inner._waited.add(i)
+            else:
+                self_inner.wait()
+
         def wait(self_inner):
-            for w in works:
-                w.wait()
+            """Everything posted has completed (a work is waited for once: gloo blocks on a second wait)."""
+            if per_op:
+                for i in range(1, ws):
+                    self_inner.wait_chunk(i)
+            elif not self_inner._waited:
+                for w in works:
+                    w.wait()
+                self_inner._waited.update(range(1, ws))
 
     return _Handle(), chunks

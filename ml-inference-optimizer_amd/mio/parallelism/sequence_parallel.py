@@ -44,6 +44,7 @@ class SequenceParallelConfig:
     exchange: str = "mesh"
     causal: bool = False
     zigzag: bool = False
+    tp_size: int = 1  # tensor-parallel degree of the same job: sequence groups stride by it (mesh of parallel_utils)
 
     def __post_init__(self):
         if self.world_size % self.sp_size != 0:
@@ -59,14 +60,25 @@ class SequenceParallelConfig:
     def get_sp_group(self) -> Optional[dist.ProcessGroup]:
         if self.sp_size == 1 and not dist.is_initialized():
             return None
-        return comm.setup_sequence_parallel_group(self.world_size, self.sp_size)
+        return comm.setup_sequence_parallel_group(self.world_size, self.sp_size, self.tp_size)
 
     def get_dp_size(self) -> int:
-        return self.world_size // self.sp_size
+        return self.world_size // (self.sp_size * self.tp_size)
 
     def get_rank_info(self) -> Tuple[int, int]:
+        """(rank inside the sequence-parallel group, data-parallel index) on the mesh rank = (dp * SP + sp) * TP + tp;
+        with registered groups (parallel_utils.initialize_parallel_groups) the group itself is asked."""
         rank = comm.get_rank()
-        return rank % self.sp_size, rank // self.sp_size
+        if dist.is_initialized() and self.sp_size > 1:
+            grp = self.get_sp_group()
+            if grp is not None:
+                from . import parallel_utils
+                tp = self.tp_size
+                if parallel_utils._PARALLEL_GROUPS:
+                    tg = parallel_utils._PARALLEL_GROUPS.get("tensor")
+                    tp = 1 if tg is None else dist.get_world_size(tg)
+                return dist.get_rank(grp), rank // (self.sp_size * tp)
+        return (rank // self.tp_size) % self.sp_size, rank // (self.sp_size * self.tp_size)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -100,13 +112,16 @@ def zigzag_unshard(shards: List[torch.Tensor], sp: int, seq_dim: int = 1) -> tor
 
 def ring_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, group: Optional[dist.ProcessGroup] = None, *,
                    layout: str = "bhsd", causal: bool = False, zigzag: bool = False, exchange: str = "mesh",
-                   softmax_scale: Optional[float] = None, additive_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   softmax_scale: Optional[float] = None, additive_mask: Optional[torch.Tensor] = None,
+                   recv_buffers: Optional[dict] = None, overlap: bool = True) -> torch.Tensor:
     """Exact attention of the local queries over the K/V shards of every rank in `group`.
 
     q/k/v are this rank's shards ([B,H,S/sp,D] for "bhsd", [B,S/sp,H,D] for "bshd"); returns the local
     output in the same layout.  Per step: one launch of the tiled kernel with the running (o fp32, lse)
     carried in and out; K/V of the next step travel meanwhile.  additive_mask (non-causal only):
-    [B,1|H,Sq_local,S_total], columns in global key order.
+    [B,1|H,Sq_local,S_total], columns in global key order.  recv_buffers: a dict kept by the caller between calls --
+    the mesh exchange then reuses its receive buffers instead of allocating sp - 1 K/V copies per call.
+    overlap=False (measurement only): every transfer completes before the attention that could have hidden it starts.
     """
     sp = comm.get_world_size(group) if dist.is_initialized() else 1
     r = comm.get_rank(group) if dist.is_initialized() else 0
@@ -172,17 +187,26 @@ def ring_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, group: Opt
     if sp == 1:
         attend(k, v, 0)
     elif exchange == "mesh":
-        handle, chunks = comm.mesh_exchange_start([k, v], group)
+        handle, chunks = comm.mesh_exchange_start([k, v], group, buffers=recv_buffers)
+        if not overlap:
+            handle.wait()
+            if q.is_cuda:
+                torch.cuda.synchronize()
         attend(k, v, 0)
-        handle.wait()
         for i in range(1, sp):
+            handle.wait_chunk(i)  # chunk i has landed (RCCL: the one grouped transfer, see mesh_exchange_start)
             attend(chunks[i][0], chunks[i][1], i)
+        handle.wait()  # every send has completed before k / v may be freed or overwritten
     else:
         # neighbour ring: step i's K/V arrive from rank-1 while step i-1 is being attended
         k_cur, v_cur = k.contiguous(), v.contiguous()
         for i in range(sp):
             if i < sp - 1:
                 h, (k_nxt, v_nxt) = comm.ring_exchange(k_cur, v_cur, group=group, async_op=True)
+                if not overlap:
+                    h.wait()
+                    if q.is_cuda:
+                        torch.cuda.synchronize()
             attend(k_cur, v_cur, i)
             if i < sp - 1:
                 h.wait()
@@ -219,11 +243,14 @@ class SequenceParallelAttention(nn.Module):
             if lin.bias is not None:
                 nn.init.zeros_(lin.bias)
         self.last_communication_time = 0.0
+        self._recv_buffers: Optional[dict] = {} if config.buffer_reuse else None  # mesh exchange receive buffers
 
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                residual: Optional[torch.Tensor] = None, pre_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
         if self.training and self.dropout_p > 0:
             raise NotImplementedError("attention dropout (training) is not supported by the inference kernel")
+        if pre_norm is not None:  # the pre-LN block's `attn(ln(x))` in one call, as FlashSelfAttention.forward takes it
+            hidden_states = _local.layernorm(hidden_states, pre_norm.weight, pre_norm.bias, pre_norm.eps)
         B, Sl, _ = hidden_states.shape
         H, D = self.num_attention_heads, self.head_dim
         q = _local.linear(hidden_states, self.query.weight, self.query.bias).view(B, Sl, H, D)
@@ -238,7 +265,7 @@ class SequenceParallelAttention(nn.Module):
             ctx = _local.attention_step(q, k, v, **kw)
         elif mode == "ring":
             ctx = ring_attention(q, k, v, self.sp_group, layout="bshd", causal=cfg.causal, zigzag=cfg.zigzag,
-                                 exchange=cfg.exchange, additive_mask=attention_mask)
+                                 exchange=cfg.exchange, additive_mask=attention_mask, recv_buffers=self._recv_buffers)
         else:  # "full": all-gather K/V then one exact attention (reference :587-640)
             t0 = time.perf_counter()
             kf = comm.all_gather(k, dim=1, group=self.sp_group)
@@ -273,7 +300,10 @@ class SequenceParallelMLP(nn.Module):
         self.dense_4h_to_h = nn.Linear(intermediate_size, hidden_size, bias=bias)
         self.activation = activation
 
-    def forward(self, hidden_states: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                pre_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
+        if pre_norm is not None:
+            hidden_states = _local.layernorm(hidden_states, pre_norm.weight, pre_norm.bias, pre_norm.eps)
         h = _local.linear(hidden_states, self.dense_h_to_4h.weight, self.dense_h_to_4h.bias, self.activation)
         return _local.linear(h, self.dense_4h_to_h.weight, self.dense_4h_to_h.bias, "none", residual)
 

@@ -59,7 +59,12 @@ class TensorParallelConfig:
         return None
 
     def tp_rank(self) -> int:
-        return comm.get_rank() % self.tp_size
+        """Rank inside the tensor-parallel group (the group is asked: adjacent ranks by default, the registered mesh
+        group after parallel_utils.initialize_parallel_groups)."""
+        if self.tp_size == 1 or not torch.distributed.is_initialized():
+            return 0
+        g = self.get_tp_group()
+        return torch.distributed.get_rank(g) if g is not None else comm.get_rank() % self.tp_size
 
 
 class ColumnParallelLinear(nn.Module):
@@ -189,14 +194,20 @@ class TensorParallelMLP(nn.Module):
         else:
             raise ValueError("activation must be F.gelu / F.relu / F.silu or a kernel activation name")
 
-    def forward(self, hidden_states: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                pre_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
+        """pre_norm (not in the reference): the pre-LN block's `mlp(ln(x))` in one call, as FusedMLP.forward takes it."""
+        if pre_norm is not None:
+            hidden_states = _local.layernorm(hidden_states, pre_norm.weight, pre_norm.bias, pre_norm.eps)
         return self.dense_4h_to_h(self.dense_h_to_4h(hidden_states), residual=residual)
 
 
 class TensorParallelAttention(nn.Module):
-    """H/tp local heads: column-parallel q/k/v (one fused GEMM), tiled attention, row-parallel out-proj
-    (reference :403-614).  The reference's `self.key = self.value = self.query` aliasing (:480-483) is
-    not reproduced."""
+    """H/tp local heads: column-parallel q/k/v, tiled attention, row-parallel out-proj (reference :403-614).
+    The three projections keep the reference's parameter names (query / key / value) but run as ONE GEMM on the
+    concatenated local weight [3 * H/tp * D, hidden] (k + v only for cross attention): at tp = 4 a single projection is
+    N = 256 -- one tile column, which cannot fill 256 CUs -- and the activation is read once instead of three times.
+    The reference's `self.key = self.value = self.query` aliasing (:480-483) is not reproduced."""
 
     def __init__(self, hidden_size: int, num_attention_heads: int, config: Optional[TensorParallelConfig] = None,
                  attention_dropout: float = 0.0, head_dim: Optional[int] = None, is_cross_attention: bool = False,
@@ -219,18 +230,43 @@ class TensorParallelAttention(nn.Module):
             self.dropout_p = attention_dropout
         else:
             self.dropout_p = 0.0
+        self._fused = {}
+
+    def _fused_weight(self, names: Tuple[str, ...]) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """Row-concatenation of the named local projections, rebuilt only when a parameter changes."""
+        lins = [getattr(self, n) for n in names]
+        key = tuple((l.weight.data_ptr(), l.weight._version, None if l.bias is None else l.bias._version,
+                     l.weight.dtype, l.weight.device) for l in lins)
+        hit = self._fused.get(names)
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        with torch.no_grad():
+            w = torch.cat([l.weight for l in lins], dim=0).contiguous()
+            b = None if lins[0].bias is None else torch.cat([l.bias for l in lins], dim=0).contiguous()
+        self._fused[names] = (key, w, b)
+        return w, b
 
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 encoder_hidden_states: Optional[torch.Tensor] = None,
-                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                residual: Optional[torch.Tensor] = None, pre_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
         if self.training and self.dropout_p > 0:
             raise NotImplementedError("attention dropout (training) is not supported by the inference kernel")
+        if pre_norm is not None:
+            hidden_states = _local.layernorm(hidden_states, pre_norm.weight, pre_norm.bias, pre_norm.eps)
         B, S, _ = hidden_states.shape
         Hl, D = self.num_heads_per_partition, self.head_dim
         kv_in = encoder_hidden_states if (self.is_cross_attention and encoder_hidden_states is not None) else hidden_states
-        q = self.query(hidden_states).view(B, S, Hl, D)
-        k = self.key(kv_in).view(B, kv_in.shape[1], Hl, D)
-        v = self.value(kv_in).view(B, kv_in.shape[1], Hl, D)
+        n = Hl * D
+        Sk = kv_in.shape[1]
+        if kv_in is hidden_states:  # self attention: one [3 n, hidden] GEMM, q / k / v are strided views of its result
+            w, b = self._fused_weight(("query", "key", "value"))
+            qkv = _local.linear(hidden_states, w, b)
+            q, k, v = (qkv[..., i * n:(i + 1) * n].view(B, S, Hl, D) for i in range(3))
+        else:
+            q = self.query(hidden_states).view(B, S, Hl, D)
+            w, b = self._fused_weight(("key", "value"))
+            kv = _local.linear(kv_in, w, b)
+            k, v = (kv[..., i * n:(i + 1) * n].view(B, Sk, Hl, D) for i in range(2))
         add = None
         if attention_mask is not None:  # additive [B,1,Sq,Sk] / [B,1,1,Sk] like the reference (:560-566)
             add = attention_mask

@@ -11,7 +11,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .kernels.attention.flash_attention import FlashAttentionConfig, FlashSelfAttention, FlashAttentionLayer
+from .kernels.attention.flash_attention import FlashAttentionConfig, FlashSelfAttention
+from .kernels.attention.ring_attention import RingAttentionConfig, RingCrossAttention
 from .kernels.mlp.fused_mlp import FusedMLPConfig, FusedTransformerMLP
 
 
@@ -21,12 +22,13 @@ class FusedLayerNorm(nn.LayerNorm):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
             raise ValueError("HIP kernels require input tensors to be on a CUDA (ROCm) device.")
-        return ops.layernorm(x, self.weight, self.bias, self.eps)
+        w = self.weight if self.weight.dtype == x.dtype else self.weight.to(x.dtype)  # fp32 parameters, 16-bit activations
+        b = self.bias if (self.bias is None or self.bias.dtype == x.dtype) else self.bias.to(x.dtype)
+        return ops.layernorm(x, w, b, self.eps)
 
 
 class Block(nn.Module):
-    def __init__(self, d: int, H: int, I: int, causal: bool, precision: str, activation: str = "gelu",
-                 cross_attention: bool = False):
+    def __init__(self, d: int, H: int, I: int, causal: bool, precision: str, activation: str = "gelu"):
         super().__init__()
         acfg = FlashAttentionConfig(causal=causal, precision=precision)
         self.ln_1 = FusedLayerNorm(d)
@@ -39,6 +41,45 @@ class Block(nn.Module):
         # output in the blocked layout the following GEMM fetches contiguously)
         x = self.attn(x, residual=x, pre_norm=self.ln_1)
         return self.mlp(x, residual=x, pre_norm=self.ln_2)
+
+
+class CrossBlock(nn.Module):
+    """Diffusion-style block of BASELINE config 5: LN -> non-causal cross attention (q from x, k / v from a separate
+    context tensor; the reference's RingCrossAttention projections, ring_attention.py:413-669) + residual -> LN ->
+    FusedMLP-GELU + residual."""
+
+    def __init__(self, d: int, H: int, I: int, precision: str = "bf16", activation: str = "gelu"):
+        super().__init__()
+        self.ln_1 = FusedLayerNorm(d)
+        self.attn = RingCrossAttention(d, H, RingAttentionConfig(precision=precision))
+        self.ln_2 = FusedLayerNorm(d)
+        self.mlp = FusedTransformerMLP(d, I, activation, FusedMLPConfig(precision=precision))
+
+    def forward(self, x: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+        x = self.attn(self.ln_1(x), context, residual=x)
+        return self.mlp(x, residual=x, pre_norm=self.ln_2)
+
+
+class CrossAttentionStack(nn.Module):
+    """L CrossBlocks over one shared context (d=1280, H=16 -> Dh 80, I=5120 is BASELINE config 5)."""
+
+    def __init__(self, hidden_size: int = 1280, num_heads: int = 16, num_layers: int = 4,
+                 intermediate_size: Optional[int] = None, precision: str = "bf16", seed: int = 0):
+        super().__init__()
+        I = intermediate_size or 4 * hidden_size
+        self.h = nn.ModuleList([CrossBlock(hidden_size, num_heads, I, precision) for _ in range(num_layers)])
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=g) * 0.02)
+                    m.bias.zero_()
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+        for blk in self.h:
+            x = blk(x, context)
+        return x
 
 
 class GPT2ShapedStack(nn.Module):

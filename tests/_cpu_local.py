@@ -51,11 +51,17 @@ def attention_step(q, k, v, *, layout="bshd", causal=False, softmax_scale=None, 
     return res
 
 
+def layernorm(x, weight, bias=None, eps=1e-5):
+    return oracle.layernorm(x, weight, bias, eps).to(x.dtype)
+
+
 def install(monkeypatch=None):
     from mio.parallelism import _local
     if monkeypatch is not None:
         monkeypatch.setattr(_local, "linear", linear)
         monkeypatch.setattr(_local, "attention_step", attention_step)
+        monkeypatch.setattr(_local, "layernorm", layernorm)
     else:
         _local.linear = linear
         _local.attention_step = attention_step
+        _local.layernorm = layernorm

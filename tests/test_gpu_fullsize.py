@@ -1,0 +1,395 @@
+"""Parity at the benchmark's own shapes (BASELINE.json configs[1] "C2" and configs[4] "C5"), through the C ABI.
+
+Every test here drives exactly the kernels bench.py times (blocked LayerNorm hand-over, blocked weights, the
+persistent 256x256 GEMM, the residual GEMM at K = 4096, fa3_fwd3 on the XCD-remapped B 8 x H 16 grid) and checks
+the values three ways:
+  1. bulk: every output element against an fp32 chain on the GPU (torch matmuls in fp32, no intermediate rounding) of
+     the same 16-bit inputs -- the sizes are far beyond what a CPU oracle finishes in seconds;
+  2. pinned chain: >= 256 sampled rows against `oracle/` (fp64 on the host), so the oracle that is pinned to the
+     reference's fixtures (tests/test_oracle_golden.py) reaches the full size;
+  3. the reference's own bf16 chain (kernels/mlp/fused_mlp.py:149-178 `F.linear -> act -> F.linear` and the
+     comparator `standard_attention`, kernels/attention/flash_attention.py:1216-1229, evaluated by torch in bf16 on the
+     same inputs): the HIP path must not be less accurate than what the reference computes in the same storage
+     dtype -- asserted as  kernel_err <= 1.25 * reference_bf16_err  on rel_err = mean|a-b| / mean|b| vs the fp32 truth.
+The measured errors are written to gpurun_out/parity_r02.json (committed copy: profiles/parity_r02.json).
+"""
+import json
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PARITY = {}
+# bf16 bars against the fp32 truth rounded to bf16 (what profiles/parity_r02.json shows, with margin)
+BF16_REL = 3e-3
+ORACLE_ROWS = 256
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_parity():
+    yield
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_r02.json"), "w") as f:
+        json.dump(PARITY, f, indent=1, sort_keys=True)
+
+
+def _ops():
+    from mio import ops
+    return ops
+
+
+def _rel(a, b):
+    """mean|a-b| / mean|b| and max|a-b| in fp32 on the device (reference ring_attention.py:1027-1029)."""
+    a, b = a.float(), b.float()
+    d = (a - b).abs()
+    return (d.mean() / b.abs().mean().clamp_min(1e-12)).item(), d.max().item()
+
+
+def _record(name, got, truth, ref16, extra=None):
+    """got: kernel output (16-bit); truth: fp32 chain; ref16: the reference's chain evaluated in the storage dtype."""
+    k_rel, k_max = _rel(got, truth)
+    r_rel, r_max = _rel(ref16, truth)
+    q_rel, q_max = _rel(truth.to(got.dtype), truth)  # pure output rounding: the floor for any 16-bit result
+    PARITY[name] = dict(kernel_rel_err=k_rel, kernel_max_abs=k_max, reference_bf16_rel_err=r_rel,
+                        reference_bf16_max_abs=r_max, rounding_floor_rel_err=q_rel, dtype=str(got.dtype), **(extra or {}))
+    assert k_rel <= 1.25 * r_rel, f"{name}: kernel rel_err {k_rel:.3e} > 1.25 x reference bf16 chain {r_rel:.3e}"
+    assert k_rel < BF16_REL, f"{name}: kernel rel_err {k_rel:.3e}"
+    return k_rel, r_rel
+
+
+def _gelu_tanh(x):
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x.pow(3))))
+
+
+def _sample_rows(M, n=ORACLE_ROWS, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.randperm(M, generator=g)[:n - 4]
+    return torch.cat([idx, torch.tensor([0, 255, 256, M - 1])])  # tile corners always included
+
+
+def _oracle_rows(name, got_rows, ref_rows, dtype):
+    ref = ref_rows.to(dtype).float()
+    got = got_rows.float().cpu()
+    rel = ((got - ref).abs().mean() / ref.abs().mean()).item()
+    PARITY[name]["oracle_rows"] = int(got_rows.shape[0])
+    PARITY[name]["oracle_rel_err"] = rel
+    assert rel < BF16_REL, f"{name}: rel_err vs oracle on sampled rows {rel:.3e}"
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# C2: B 8, S 4096, d 1024, H 16, I 4096, bf16, causal
+# ----------------------------------------------------------------------------------------------------------------
+C2 = dict(B=8, S=4096, d=1024, H=16, I=4096)
+
+
+def _c2_inputs(seed, *shapes, scale=1.0):
+    torch.manual_seed(seed)
+    return [(torch.randn(*s, device=DEV) * scale).to(torch.bfloat16) for s in shapes]
+
+
+def test_c2_qkv_gemm_blocked_handover():
+    """LN1 -> QKV projection exactly as the stack runs it: LayerNorm writes the blocked activation layout, the
+    persistent kernel (M 32768, N 3072, K 1024) reads blocked x and blocked W."""
+    ops = _ops()
+    B, S, d = C2["B"], C2["S"], C2["d"]
+    M, N = B * S, 3 * d
+    (x,) = _c2_inputs(1, (B, S, d))
+    g, be = _c2_inputs(2, (d,), (d,), scale=0.1)
+    g = (g.float() + 1).to(torch.bfloat16)
+    (w,) = _c2_inputs(3, (N, d), scale=0.02)
+    (b,) = _c2_inputs(4, (N,), scale=0.02)
+    xn = ops.layernorm(x, g, be)
+    xb = ops.layernorm(x, g, be, out_blocked=True)
+    wb = ops.block_weight(w)
+    assert ops.blocked_weight_ok(M, N, d, "none")
+    y = ops.gemm_bias_act(xb, w, b, w_blocked=wb, x_blocked_shape=(B, S, d))
+    y_plain = ops.gemm_bias_act(xn, w, b, w_blocked=wb)
+    assert torch.equal(y, y_plain)  # blocked hand-over: same kernel arithmetic, same bits
+    truth = xn.float().view(M, d) @ w.float().T + b.float()
+    ref16 = F.linear(xn, w, b).view(M, N)
+    _record("c2_qkv_gemm M32768 N3072 K1024", y.view(M, N), truth, ref16)
+    rows = _sample_rows(M)
+    want = F.linear(xn.view(M, d)[rows].cpu().double(), w.cpu().double(), b.cpu().double())
+    _oracle_rows("c2_qkv_gemm M32768 N3072 K1024", y.view(M, N)[rows], want, torch.bfloat16)
+    # LayerNorm itself at this size vs the oracle rows
+    ln_want = oracle.layernorm(x.view(M, d)[rows].cpu(), g.cpu(), be.cpu(), 1e-5)
+    rel = ((xn.view(M, d)[rows].float().cpu() - ln_want.to(torch.bfloat16).float()).abs().mean()
+           / ln_want.abs().mean()).item()
+    PARITY["c2_layernorm rows32768 cols1024"] = dict(oracle_rows=int(rows.numel()), oracle_rel_err=rel)
+    assert rel < BF16_REL
+
+
+def test_c2_out_proj_residual():
+    """Attention out-projection + residual (M 32768, N 1024, K 1024): the one-tile 256x256 residual kernel."""
+    ops = _ops()
+    B, S, d = C2["B"], C2["S"], C2["d"]
+    M = B * S
+    ctx, r = _c2_inputs(5, (B, S, d), (B, S, d))
+    (w,) = _c2_inputs(6, (d, d), scale=0.02)
+    (b,) = _c2_inputs(7, (d,), scale=0.02)
+    wb = ops.block_weight(w)
+    y = ops.gemm_bias_act(ctx, w, b, residual=r, w_blocked=wb)
+    truth = ctx.float().view(M, d) @ w.float().T + b.float() + r.float().view(M, d)
+    ref16 = (F.linear(ctx, w, b) + r).view(M, d)
+    _record("c2_out_proj+residual M32768 N1024 K1024", y.view(M, d), truth, ref16)
+    rows = _sample_rows(M, seed=1)
+    want = F.linear(ctx.view(M, d)[rows].cpu().double(), w.cpu().double(), b.cpu().double()) + r.view(M, d)[rows].cpu().double()
+    _oracle_rows("c2_out_proj+residual M32768 N1024 K1024", y.view(M, d)[rows], want, torch.bfloat16)
+
+
+def test_c2_fused_mlp_bench_shape():
+    """FusedMLP as bench.py runs it: fc1 (M 32768, N 4096, K 1024) + tanh-GELU on the persistent kernel writing the
+    blocked intermediate, fc2 (N 1024, K 4096 = 128 K-tiles through the 4-stage ring) + bias + residual, blocked
+    LayerNorm hand-over and blocked weights."""
+    ops = _ops()
+    B, S, d, I = C2["B"], C2["S"], C2["d"], C2["I"]
+    M = B * S
+    x, r = _c2_inputs(8, (B, S, d), (B, S, d))
+    g, be = _c2_inputs(9, (d,), (d,), scale=0.1)
+    g = (g.float() + 1).to(torch.bfloat16)
+    w1, w2 = _c2_inputs(10, (I, d), (d, I), scale=0.02)
+    b1, b2 = _c2_inputs(11, (I,), (d,), scale=0.02)
+    xn = ops.layernorm(x, g, be)
+    xb = ops.layernorm(x, g, be, out_blocked=True)
+    w1b, w2b = ops.block_weight(w1), ops.block_weight(w2)
+    assert ops.fused_mlp_blocked_weight_ok(M, d, I, "gelu")
+    y = ops.fused_mlp(xb, w1, b1, w2, b2, "gelu", residual=r, fc1_blocked=w1b, fc2_blocked=w2b, x_blocked_shape=(B, S, d))
+    y_plain = ops.fused_mlp(xn, w1, b1, w2, b2, "gelu", residual=r, fc1_blocked=w1b, fc2_blocked=w2b)
+    assert torch.equal(y, y_plain)
+    h = _gelu_tanh(xn.float().view(M, d) @ w1.float().T + b1.float())
+    truth = h @ w2.float().T + b2.float() + r.float().view(M, d)
+    del h
+    ref16 = (F.linear(F.gelu(F.linear(xn, w1, b1), approximate="tanh"), w2, b2) + r).view(M, d)
+    _record("c2_fused_mlp gelu M32768 d1024 I4096 +residual", y.view(M, d), truth, ref16)
+    rows = _sample_rows(M, seed=2)
+    want = oracle.fused_mlp(xn.view(M, d)[rows].cpu(), w1.cpu(), b1.cpu(), w2.cpu(), b2.cpu(), "gelu",
+                            residual=r.view(M, d)[rows].cpu())
+    _oracle_rows("c2_fused_mlp gelu M32768 d1024 I4096 +residual", y.view(M, d)[rows], want, torch.bfloat16)
+    # stage 1 alone (fc1 + GELU, N 4096): the intermediate the second GEMM consumes
+    h1 = ops.gemm_bias_act(xb, w1, b1, "gelu", w_blocked=w1b, x_blocked_shape=(B, S, d)).view(M, I)
+    truth1 = _gelu_tanh(xn.float().view(M, d) @ w1.float().T + b1.float())
+    ref1 = F.gelu(F.linear(xn, w1, b1), approximate="tanh").view(M, I)
+    _record("c2_fc1+gelu M32768 N4096 K1024", h1, truth1, ref1)
+
+
+def _attention_truth(q, k, v, causal, chunk_b=1):
+    """fp32 softmax(q k^T / sqrt(D)) v on the GPU, [B,S,H,D] in / out (the reference comparator's math,
+    flash_attention.py:1216-1229, with -inf instead of -1e9: identical after softmax)."""
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    out = torch.empty(B, Sq, H, D, device=q.device, dtype=torch.float32)
+    tri = torch.triu(torch.ones(Sq, Sk, device=q.device, dtype=torch.bool), 1) if causal else None
+    for b in range(0, B, chunk_b):
+        qf, kf, vf = (t[b:b + chunk_b].float().permute(0, 2, 1, 3) for t in (q, k, v))
+        s = (qf @ kf.transpose(-1, -2)) / math.sqrt(D)
+        if tri is not None:
+            s = s.masked_fill(tri, float("-inf"))
+        out[b:b + chunk_b] = (torch.softmax(s, -1) @ vf).permute(0, 2, 1, 3)
+    return out
+
+
+def _attention_ref16(q, k, v, causal):
+    """The reference's `standard_attention` evaluated in the storage dtype (flash_attention.py:1216-1229)."""
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    out = torch.empty_like(q)
+    tri = torch.triu(torch.ones(Sq, Sk, device=q.device, dtype=torch.bool), 1) if causal else None
+    for b in range(B):
+        scores = torch.einsum("bshd,bkhd->bhsk", q[b:b + 1], k[b:b + 1]) / math.sqrt(D)
+        if tri is not None:
+            scores.masked_fill_(tri[None, None], -1e9)
+        out[b:b + 1] = torch.einsum("bhsk,bkhd->bshd", F.softmax(scores, dim=-1), v[b:b + 1])
+    return out
+
+
+def _attention_oracle_rows(name, o, lse, q, k, v, causal, n=ORACLE_ROWS, seed=0):
+    """oracle.attention_with_lse on sampled (batch, head, query row) triples: the query row against the keys it sees."""
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    g = torch.Generator().manual_seed(seed)
+    bs = torch.randint(0, B, (n,), generator=g)
+    hs = torch.randint(0, H, (n,), generator=g)
+    rs = torch.randint(0, Sq, (n,), generator=g)
+    rs[:4] = torch.tensor([0, 255, 256, Sq - 1])
+    Hkv = k.shape[2]
+    got, want, dl = [], [], 0.0
+    qc, kc, vc = q.cpu(), k.cpu(), v.cpu()
+    oc, lc = o.cpu(), lse.cpu()
+    for b, h, r in zip(bs.tolist(), hs.tolist(), rs.tolist()):
+        hk = h // (H // Hkv)
+        nk = min(r + 1, Sk) if causal else Sk
+        ref, rl = oracle.attention_with_lse(qc[b:b + 1, r:r + 1, h:h + 1], kc[b:b + 1, :nk, hk:hk + 1],
+                                            vc[b:b + 1, :nk, hk:hk + 1], causal=False)
+        got.append(oc[b, r, h].float())
+        want.append(ref[0, 0, 0].to(o.dtype).float())
+        dl = max(dl, abs(float(lc[b, h, r]) - float(rl[0, 0, 0])))
+    got, want = torch.stack(got), torch.stack(want)
+    rel = ((got - want).abs().mean() / want.abs().mean()).item()
+    PARITY[name]["oracle_rows"] = n
+    PARITY[name]["oracle_rel_err"] = rel
+    PARITY[name]["oracle_lse_max_abs"] = dl
+    assert rel < BF16_REL, f"{name}: rel_err vs oracle rows {rel:.3e}"
+    assert dl < 6e-3, f"{name}: lse max|d| {dl:.3e}"
+
+
+def test_c2_attention_b8_h16_s4096_causal():
+    """fa3_fwd3 on the benchmark grid: B 8 x H 16 = 128 (batch, head) pairs with the XCD remap, S 4096, D 64, causal,
+    q / k / v as strided views of one fused [B,S,3d] projection result (as FlashSelfAttention hands them over)."""
+    ops = _ops()
+    B, S, H, d = C2["B"], C2["S"], C2["H"], C2["d"]
+    D = d // H
+    (qkv,) = _c2_inputs(12, (B, S, 3 * d))
+    q, k, v = (qkv[:, :, i * d:(i + 1) * d].view(B, S, H, D) for i in range(3))
+    o, lse = ops.fa3_fwd(q, k, v, causal=True, return_lse=True)
+    truth = _attention_truth(q, k, v, True)
+    ref16 = _attention_ref16(q, k, v, True)
+    name = "c2_attention B8 H16 S4096 D64 causal"
+    _record(name, o, truth, ref16)
+    _attention_oracle_rows(name, o, lse, q, k, v, True)
+
+
+def test_c2_block_b8_s4096():
+    """One full pre-LN block of the benchmark stack (LN -> QKV -> causal attention -> out-proj + residual -> LN ->
+    fc1 + GELU -> fc2 + residual) at B 8, S 4096 against the unrounded fp32 chain, the reference's bf16 chain, and
+    the oracle on sampled rows of one batch element."""
+    from mio.synthetic import Block
+    B, S, d, H, I = C2["B"], C2["S"], C2["d"], C2["H"], C2["I"]
+    D = d // H
+    torch.manual_seed(0)
+    blk = Block(d, H, I, causal=True, precision="bf16")
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.weight.copy_(torch.randn(m.weight.shape) * 0.02)
+                m.bias.copy_(torch.randn(m.bias.shape) * 0.02)
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.copy_(1 + 0.1 * torch.randn(m.weight.shape))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape))
+    blk = blk.to(device=DEV, dtype=torch.bfloat16).eval()
+    (x,) = _c2_inputs(13, (B, S, d))
+    with torch.no_grad():
+        y = blk(x)
+
+    def chain(dt):
+        f = lambda t: t.to(dt)
+        with torch.no_grad():
+            h = F.layer_norm(f(x), (d,), f(blk.ln_1.weight), f(blk.ln_1.bias), blk.ln_1.eps)
+            qkv = F.linear(h, f(blk.attn.qkv_proj.weight), f(blk.attn.qkv_proj.bias))
+            q, k, v = (qkv[:, :, i * d:(i + 1) * d].reshape(B, S, H, D) for i in range(3))
+            ctx = (_attention_truth(q, k, v, True) if dt == torch.float32 else _attention_ref16(q, k, v, True)).to(dt)
+            a = F.linear(ctx.view(B, S, d), f(blk.attn.o_proj.weight), f(blk.attn.o_proj.bias)) + f(x)
+            h2 = F.layer_norm(a, (d,), f(blk.ln_2.weight), f(blk.ln_2.bias), blk.ln_2.eps)
+            m = F.linear(F.gelu(F.linear(h2, f(blk.mlp.mlp.fc1.weight), f(blk.mlp.mlp.fc1.bias)), approximate="tanh"),
+                         f(blk.mlp.mlp.fc2.weight), f(blk.mlp.mlp.fc2.bias))
+            return m + a
+
+    truth = chain(torch.float32)
+    ref16 = chain(torch.bfloat16)
+    name = "c2_block B8 S4096 d1024 H16 I4096"
+    _record(name, y.view(-1, d), truth.view(-1, d), ref16.view(-1, d))
+    # oracle (fp64 on the host) for sampled rows of batch element 3: K/V of the whole sequence, the rest per row
+    b0, n = 3, 64
+    rows = torch.cat([torch.randperm(S, generator=torch.Generator().manual_seed(4))[:n - 3], torch.tensor([0, 255, S - 1])])
+    c = lambda t: t.detach().cpu().double()
+    xs = x[b0].cpu()
+    h = oracle.layernorm(xs, blk.ln_1.weight.cpu(), blk.ln_1.bias.cpu(), blk.ln_1.eps)
+    wqkv, bqkv = c(blk.attn.qkv_proj.weight), c(blk.attn.qkv_proj.bias)
+    kv = F.linear(h.double(), wqkv[d:], bqkv[d:])                       # [S, 2d]
+    qs = F.linear(h.double()[rows], wqkv[:d], bqkv[:d])                  # [n, d]
+    ctx = torch.empty(n, d, dtype=torch.float64)
+    for i, r in enumerate(rows.tolist()):
+        kk = kv[:r + 1, :d].view(1, r + 1, H, D)
+        vv = kv[:r + 1, d:].view(1, r + 1, H, D)
+        ctx[i] = oracle.standard_attention(qs[i].view(1, 1, H, D), kk, vv, causal=False).view(d)
+    a = F.linear(ctx, c(blk.attn.o_proj.weight), c(blk.attn.o_proj.bias)) + xs.double()[rows]
+    h2 = oracle.layernorm(a, blk.ln_2.weight.cpu(), blk.ln_2.bias.cpu(), blk.ln_2.eps)
+    want = oracle.fused_mlp(h2, blk.mlp.mlp.fc1.weight.cpu(), blk.mlp.mlp.fc1.bias.cpu(), blk.mlp.mlp.fc2.weight.cpu(),
+                            blk.mlp.mlp.fc2.bias.cpu(), "gelu", residual=a)
+    _oracle_rows(name, y[b0][rows], want, torch.bfloat16)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# C5: non-causal (cross-)attention d 1280, H 16 -> Dh 80, S 4096, FusedMLP-GELU I 5120
+# ----------------------------------------------------------------------------------------------------------------
+C5 = dict(B=2, S=4096, d=1280, H=16, I=5120)
+
+
+@pytest.mark.parametrize("Sk", [4096, 1613])
+def test_c5_attention_dh80(Sk):
+    """Head dim 80 (padded to the 96 instantiation), non-causal: Sq = Sk = 4096 and a ragged cross-attention context."""
+    ops = _ops()
+    B, S, H, d = C5["B"], C5["S"], C5["H"], C5["d"]
+    D = d // H
+    q, = _c2_inputs(20, (B, S, H, D))
+    k, v = _c2_inputs(21 + Sk, (B, Sk, H, D), (B, Sk, H, D))
+    o, lse = ops.fa3_fwd(q, k, v, causal=False, return_lse=True)
+    name = f"c5_attention B2 H16 Sq4096 Sk{Sk} D80 non-causal"
+    _record(name, o, _attention_truth(q, k, v, False), _attention_ref16(q, k, v, False))
+    _attention_oracle_rows(name, o, lse, q, k, v, False, seed=Sk)
+
+
+def test_c5_fused_mlp_gelu():
+    ops = _ops()
+    B, S, d, I = C5["B"], C5["S"], C5["d"], C5["I"]
+    M = B * S
+    x, r = _c2_inputs(30, (B, S, d), (B, S, d))
+    w1, w2 = _c2_inputs(31, (I, d), (d, I), scale=0.02)
+    b1, b2 = _c2_inputs(32, (I,), (d,), scale=0.02)
+    blocked = ops.fused_mlp_blocked_weight_ok(M, d, I, "gelu")
+    kw = dict(fc1_blocked=ops.block_weight(w1), fc2_blocked=ops.block_weight(w2)) if blocked else {}
+    y = ops.fused_mlp(x, w1, b1, w2, b2, "gelu", residual=r, **kw)
+    truth = _gelu_tanh(x.float().view(M, d) @ w1.float().T + b1.float()) @ w2.float().T + b2.float() + r.float().view(M, d)
+    ref16 = (F.linear(F.gelu(F.linear(x, w1, b1), approximate="tanh"), w2, b2) + r).view(M, d)
+    name = "c5_fused_mlp gelu M8192 d1280 I5120 +residual"
+    _record(name, y.view(M, d), truth, ref16, extra=dict(blocked_weights=bool(blocked)))
+    rows = _sample_rows(M, seed=5)
+    want = oracle.fused_mlp(x.view(M, d)[rows].cpu(), w1.cpu(), b1.cpu(), w2.cpu(), b2.cpu(), "gelu",
+                            residual=r.view(M, d)[rows].cpu())
+    _oracle_rows(name, y.view(M, d)[rows], want, torch.bfloat16)
+
+
+def test_c5_cross_block():
+    """The C5 block bench.py --workload c5 times: LN -> cross attention (q from x, k / v from a separate context,
+    RingCrossAttention projections) + residual -> LN -> FusedMLP GELU + residual, against the fp32 chain."""
+    from mio.synthetic import CrossBlock
+    B, S, d, H, I = C5["B"], C5["S"], C5["d"], C5["H"], C5["I"]
+    D, Sk = d // H, 1024 + 77
+    torch.manual_seed(1)
+    blk = CrossBlock(d, H, I, precision="bf16")
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.weight.copy_(torch.randn(m.weight.shape) * 0.02)
+                m.bias.copy_(torch.randn(m.bias.shape) * 0.02)
+    blk = blk.to(device=DEV, dtype=torch.bfloat16).eval()
+    x, = _c2_inputs(40, (B, S, d))
+    ctx_in, = _c2_inputs(41, (B, Sk, d))
+    with torch.no_grad():
+        y = blk(x, ctx_in)
+
+    def chain(dt):
+        f = lambda t: t.to(dt)
+        at = blk.attn
+        with torch.no_grad():
+            h = F.layer_norm(f(x), (d,), f(blk.ln_1.weight), f(blk.ln_1.bias), blk.ln_1.eps)
+            q = F.linear(h, f(at.q_proj.weight), f(at.q_proj.bias)).view(B, S, H, D)
+            k = F.linear(f(ctx_in), f(at.k_proj.weight), f(at.k_proj.bias)).view(B, Sk, H, D)
+            v = F.linear(f(ctx_in), f(at.v_proj.weight), f(at.v_proj.bias)).view(B, Sk, H, D)
+            c = (_attention_truth(q, k, v, False) if dt == torch.float32 else _attention_ref16(q, k, v, False)).to(dt)
+            a = F.linear(c.view(B, S, d), f(at.out_proj.weight), f(at.out_proj.bias)) + f(x)
+            h2 = F.layer_norm(a, (d,), f(blk.ln_2.weight), f(blk.ln_2.bias), blk.ln_2.eps)
+            m = F.linear(F.gelu(F.linear(h2, f(blk.mlp.mlp.fc1.weight), f(blk.mlp.mlp.fc1.bias)), approximate="tanh"),
+                         f(blk.mlp.mlp.fc2.weight), f(blk.mlp.mlp.fc2.bias))
+            return m + a
+
+    _record("c5_cross_block B2 Sq4096 Sk1101 d1280 H16 I5120", y.view(-1, d), chain(torch.float32).view(-1, d),
+            chain(torch.bfloat16).view(-1, d))

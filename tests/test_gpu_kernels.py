@@ -3,9 +3,12 @@
 Tolerances (stated per the north star's "bf16/fp16 tolerance"):
   rel_err = mean|a-b| / mean|b|  (reference ring_attention.py:1027-1029) against the oracle evaluated in
   fp64 on the same bf16/fp16 inputs and rounded to the storage dtype like the kernel output:
-      fp16: rel_err < 1e-3, max|d| < 4e-3      bf16: rel_err < 4e-3, max|d| < 3e-2
-  (bf16 has 8 significant bits: one ulp of an O(1) output is 7.8e-3, so "max|d| < 1e-3" of the
-  reference's fp32 self-checks is not representable in bf16 storage; the fp16 row is the 1e-3 bar.)
+      fp16: rel_err < 1e-3, max|d| < 4e-3      bf16: rel_err < 3e-3, max|d| < 2e-2
+  (bf16 has 8 significant bits: one ulp of an O(1) output is 7.8e-3 and rounding alone gives rel_err 1.4e-3, so the
+  reference's fp32 "max|d| < 1e-3" is not representable in bf16 storage; the fp16 row is the 1e-3 bar.  The bf16 bar
+  is what profiles/parity_r02.json shows at the benchmark shapes -- kernel 1.4e-3 .. 2.5e-3 against the unrounded
+  fp32 chain, the reference's own bf16 chain 1.4e-3 .. 5.6e-3 on the same inputs -- with margin;
+  tests/test_gpu_fullsize.py asserts kernel_err <= 1.25 x reference_bf16_err case by case.)
 """
 import os
 
@@ -18,7 +21,7 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
-TOL = {torch.float16: (1e-3, 4e-3), torch.bfloat16: (4e-3, 3e-2)}
+TOL = {torch.float16: (1e-3, 4e-3), torch.bfloat16: (3e-3, 2e-2)}
 
 
 def _ops():
@@ -232,7 +235,7 @@ def test_fused_mlp_vs_oracle(dtype, act, B, S, d, I):
     got = y.float().cpu()
     refd = ref.to(dtype).float()
     rel = ((got - refd).abs().mean() / refd.abs().mean()).item()
-    assert rel < (2e-3 if dtype == torch.float16 else 1e-2), f"rel_err={rel:.3e}"
+    assert rel < (2e-3 if dtype == torch.float16 else 5e-3), f"rel_err={rel:.3e}"
 
 
 @pytest.mark.parametrize("name,act", [("gelu", "gelu"), ("swiglu", "swiglu"), ("relu", "relu"), ("silu", "silu"),
@@ -298,7 +301,7 @@ def test_fused_mlp_blocked_intermediate(dtype, act, res, M):
     if r is not None:
         ref = ref + r[0].double()
     rel = ((y[0].float().cpu().double() - ref).abs().mean() / ref.abs().mean()).item()
-    assert rel < (2e-3 if dtype == torch.float16 else 1e-2), f"rel_err={rel:.3e}"
+    assert rel < (2e-3 if dtype == torch.float16 else 5e-3), f"rel_err={rel:.3e}"
     assert ops.fused_mlp_blocked_weight_ok(M, d, I, act)
     y2 = ops.fused_mlp(x.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), act,
                        residual=None if r is None else r.to(DEV),
@@ -449,13 +452,11 @@ def test_paged_decode_and_cache(dtype, D, H, Hkv, q_len):
     _cmp(out, oracle.paged_attention_forward(q, kc, vc, bt, ctx2, bs, 1), dtype, "paged+1")
 
 
-@pytest.mark.parametrize("unroll", ["1", "2", "4", "8"])
-def test_paged_decode_pipelined_batches(unroll, monkeypatch):
-    """Ragged contexts long enough for several double-buffered batches and the split + reduce path, at every
-    unroll factor the launcher can pick (MIO_DEC_U is read per call); contexts that end inside a batch, inside a
-    block, at a split boundary, and one empty sequence."""
+def test_paged_decode_pipelined_batches():
+    """Ragged contexts long enough for several double-buffered batches and the split + reduce path; contexts that
+    end inside a batch, inside a block, at a split boundary, and one empty sequence."""
     ops = _ops()
-    monkeypatch.setenv("MIO_DEC_U", unroll)
+    unroll = "2"
     torch.manual_seed(7)
     dtype = torch.bfloat16
     for D, H, Hkv in ((64, 4, 4), (128, 4, 2)):
@@ -492,3 +493,31 @@ def test_errors_raise_before_launch():
         ops.fused_mlp(x, w1, None, w2, None, "tanh")
     with pytest.raises(ValueError):
         ops.flash_attention(q.float(), q.float(), q.float())
+    # per-column operands and residuals are read through raw pointers: dtype / length / contiguity are checked first
+    xl = torch.randn(2, 8, 64, dtype=torch.bfloat16, device=DEV)
+    wl = torch.ones(64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ValueError):
+        ops.layernorm(xl, wl.float())                      # fp32 nn.LayerNorm weight with bf16 activations
+    with pytest.raises(ValueError):
+        ops.layernorm(xl, wl[:32])                         # shorter than cols: would be an out-of-bounds device read
+    with pytest.raises(ValueError):
+        ops.layernorm(xl, torch.ones(128, dtype=torch.bfloat16, device=DEV)[::2])  # not contiguous
+    with pytest.raises(ValueError):
+        ops.layernorm(xl, wl, wl.float())
+    with pytest.raises(ValueError):
+        ops.layernorm(xl, wl, residual=xl.float())
+    wg = torch.randn(32, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ValueError):
+        ops.gemm_bias_act(xl, wg, torch.zeros(32, device=DEV))               # fp32 bias
+    with pytest.raises(ValueError):
+        ops.gemm_bias_act(xl, wg, torch.zeros(16, dtype=torch.bfloat16, device=DEV))  # short bias
+    with pytest.raises(ValueError):
+        ops.gemm_bias_act(xl, wg, residual=torch.zeros(2, 8, 32, device=DEV))  # fp32 residual
+    w1b = torch.randn(128, 64, dtype=torch.bfloat16, device=DEV)
+    w2b = torch.randn(64, 128, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ValueError):
+        ops.fused_mlp(xl, w1b, torch.zeros(128, device=DEV), w2b, None)      # fp32 fc1 bias
+    with pytest.raises(ValueError):
+        ops.fused_mlp(xl, w1b, None, w2b, torch.zeros(32, dtype=torch.bfloat16, device=DEV))  # short fc2 bias
+    with pytest.raises(ValueError):
+        ops.fused_mlp(xl, w1b, None, w2b, None, residual=xl.float())

@@ -42,10 +42,10 @@ def test_attention_layers(dtype, prec, cls):
         q, k, v = qkv[..., :d], qkv[..., d:d + Hkv * D], qkv[..., d + Hkv * D:]
     ctx = oracle.standard_attention(q.view(B, S, H, D), k.reshape(B, S, Hkv, D), v.reshape(B, S, Hkv, D), causal=True)
     ref = F.linear(ctx.reshape(B, S, d), sd["o_proj.weight"], sd["o_proj.bias"])
-    assert _rel(y, ref) < (2e-2 if dtype == torch.bfloat16 else 3e-3)
+    assert _rel(y, ref) < (6e-3 if dtype == torch.bfloat16 else 3e-3)  # 4 chained 16-bit roundings (q/k/v, ctx, out)
     # fp32 activations with 16-bit precision configured: cast in, cast back (flash_attention.py:176-225)
     y32 = m.float()(x.float())
-    assert y32.dtype == torch.float32 and _rel(y32, ref) < 2e-2
+    assert y32.dtype == torch.float32 and _rel(y32, ref) < 6e-3
 
 
 def test_flash_attention3_module_and_mask():
@@ -101,7 +101,7 @@ def test_optimizer_facade_end_to_end():
                                     use_custom_layernorm=True, causal=True)
     with torch.no_grad():
         y = opt(x.to(DEV, torch.bfloat16))
-    assert _rel(y, ref) < 2e-2 and (y.float().cpu() - ref).abs().max() < 0.15
+    assert _rel(y, ref) < 1e-2 and (y.float().cpu() - ref).abs().max() < 0.15  # fp32 weights vs their bf16 copies: weight rounding included
 
 
 def test_synthetic_stack_matches_plain_stack():
@@ -126,7 +126,7 @@ def test_synthetic_stack_matches_plain_stack():
     with torch.no_grad():
         ref = plain(x)
         y = fast.to(DEV, torch.bfloat16)(x.to(DEV, torch.bfloat16))
-    assert _rel(y, ref) < 2e-2
+    assert _rel(y, ref) < 1e-2  # fp32 weights vs their bf16 copies through 3 layers: weight rounding included
 
 
 def test_mlp_converter_module_on_gpu():

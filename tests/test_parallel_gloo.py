@@ -47,6 +47,15 @@ def _w_collectives(rank, world):
     t = torch.full((4, 3), float(rank + 1))
     assert torch.equal(comm.all_reduce(t.clone(), "sum"), torch.full((4, 3), float(sum(range(1, world + 1)))))
     assert torch.allclose(comm.all_reduce(t.clone(), "avg"), torch.full((4, 3), (world + 1) / 2.0))
+    # asynchronous form with a wire dtype and "avg": the handle's wait() must copy back and divide
+    t32 = torch.full((4, 3), float(rank + 1))
+    h, same = comm.all_reduce(t32, "avg", async_op=True, use_bf16=True)
+    assert same is t32
+    h.wait()
+    assert torch.allclose(t32, torch.full((4, 3), (world + 1) / 2.0)) and h.is_completed()
+    h, t2 = comm.all_reduce(torch.full((2,), float(rank)), "sum", async_op=True)
+    h.wait()
+    assert t2[0].item() == sum(range(world))
     g = comm.all_gather(torch.full((2, 3), float(rank)), dim=1)
     assert g.shape == (2, 3 * world) and all(torch.equal(g[:, 3 * r:3 * r + 3], torch.full((2, 3), float(r))) for r in range(world))
     rs = comm.reduce_scatter(torch.arange(4 * world, dtype=torch.float32).view(2 * world, 2), dim=0)
@@ -58,6 +67,20 @@ def _w_collectives(rank, world):
     h.wait()
     for i in range(world):
         assert torch.equal(chunks[i][0], torch.full((2,), float((rank - i) % world)))
+    # per-origin waits + receive buffers kept between calls (SequenceParallelConfig.buffer_reuse)
+    pool = {}
+    h, chunks = comm.mesh_exchange_start([torch.full((2,), float(rank)), torch.full((3,), 10.0 + rank)], buffers=pool)
+    for i in range(1, world):
+        h.wait_chunk(i)
+        assert torch.equal(chunks[i][0], torch.full((2,), float((rank - i) % world)))
+        assert torch.equal(chunks[i][1], torch.full((3,), 10.0 + (rank - i) % world))
+    h.wait()
+    first = [b.data_ptr() for c in chunks[1:] for b in c]
+    dist.barrier()
+    h, chunks = comm.mesh_exchange_start([torch.full((2,), 5.0 * rank), torch.full((3,), 7.0 + rank)], buffers=pool)
+    h.wait()
+    assert [b.data_ptr() for c in chunks[1:] for b in c] == first and len(pool) == 1
+    assert torch.equal(chunks[world - 1][0], torch.full((2,), 5.0 * ((rank + 1) % world)))
     x = torch.arange(2 * 8 * 3, dtype=torch.float32).view(2, 8, 3)
     loc = comm.scatter_along_sequence_dim(x, world)
     assert torch.equal(loc, x[:, rank * (8 // world):(rank + 1) * (8 // world)])
@@ -205,6 +228,44 @@ def _w_tp_x_sp(rank, world):
     assert torch.allclose(y, y_dense[:, ss], atol=1e-4)
 
 
+def _w_tp_x_sp_configs(rank, world):
+    """The config objects alone (no initialize_parallel_groups) on a tensor (2) x sequence (2) job: the tensor groups
+    are adjacent ranks, the sequence groups stride by tp_size; a sequence config that does not know about the tensor
+    groups is refused instead of silently ringing over ranks that hold different heads of the same tokens.  Then the
+    block: ring attention over the sequence group on this rank's heads, row-parallel out-projection over the tensor
+    group == the dense result for the rank's tokens."""
+    import oracle
+    from mio.parallelism import (RowParallelLinear, SequenceParallelConfig, TensorParallelConfig)
+    from mio.parallelism import communication as comm
+    from mio.parallelism.sequence_parallel import ring_attention
+    tcfg = TensorParallelConfig(world_size=world, tp_size=2)
+    tg = tcfg.get_tp_group()
+    assert [dist.get_global_rank(tg, i) for i in range(2)] == [rank - rank % 2, rank - rank % 2 + 1]
+    with pytest.raises(RuntimeError):
+        SequenceParallelConfig(world_size=world, sp_size=2).get_sp_group()
+    scfg = SequenceParallelConfig(world_size=world, sp_size=2, tp_size=2, exchange="mesh")
+    sg = scfg.get_sp_group()
+    assert sorted(dist.get_global_rank(sg, i) for i in range(2)) == [rank % 2, rank % 2 + 2]
+    assert scfg.get_rank_info() == (rank // 2, 0) and tcfg.tp_rank() == rank % 2 and scfg.get_dp_size() == 1
+    tp_r, sp_r = tcfg.tp_rank(), scfg.get_rank_info()[0]
+    torch.manual_seed(0)
+    B, S, H, D = 1, 32, 4, 8
+    d = H * D
+    q, k, v = (torch.randn(B, S, H, D) for _ in range(3))
+    wo, bo = torch.randn(d, d) * 0.1, torch.randn(d) * 0.1
+    dense = torch.nn.functional.linear(oracle.standard_attention(q, k, v).reshape(B, S, d).float(), wo, bo)
+    hs = slice(tp_r * H // 2, (tp_r + 1) * H // 2)
+    ss = slice(sp_r * S // 2, (sp_r + 1) * S // 2)
+    o = ring_attention(q[:, ss, hs].contiguous(), k[:, ss, hs].contiguous(), v[:, ss, hs].contiguous(), sg,
+                       layout="bshd", exchange="mesh", recv_buffers={})
+    row = RowParallelLinear(d, d, True, tcfg, input_is_parallel=True)
+    with torch.no_grad():
+        row.weight.copy_(wo[:, tp_r * d // 2:(tp_r + 1) * d // 2])
+        row.bias.copy_(bo)
+    y = row(o.reshape(B, S // 2, d // 2))
+    assert torch.allclose(y, dense[:, ss], atol=1e-4)
+
+
 def test_collectives_ws2():
     _run("_w_collectives", 2)
 
@@ -240,3 +301,7 @@ def test_sequence_parallel_modules_ws2():
 
 def test_tensor_x_sequence_groups_ws4():
     _run("_w_tp_x_sp", world=4)
+
+
+def test_tensor_x_sequence_configs_ws4():
+    _run("_w_tp_x_sp_configs", world=4)

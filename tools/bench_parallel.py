@@ -36,11 +36,14 @@ class _TPBlock(nn.Module):
         return self.mlp(self.ln_2(x), residual=x)
 
 
-def bench_tp(N, B, S, d, H, I, L, dt, steps=3, warmup=1):
-    """Same global work as the single-GPU benchmark (B sequences), weights sharded tp=N."""
+def bench_tp(N, tp, B, S, d, H, I, L, dt, steps=3, warmup=1):
+    """BASELINE config 3: the 1-GPU workload (B sequences of S tokens) per tensor-parallel group of `tp` adjacent ranks
+    (N / tp such groups run side by side on different data): column-parallel QKV / fc1, row-parallel out-proj / fc2 +
+    all-reduce SUM on the group (reference tensor_parallel.py:299-308), with the all-reduce of row chunk i under the GEMM
+    of chunk i + 1 ("overlapped") and as one blocking call after the whole GEMM ("unoverlapped")."""
     from mio.parallelism import TensorParallelConfig
 
-    cfg = TensorParallelConfig(world_size=N, tp_size=N, overlap_chunks=4)
+    cfg = TensorParallelConfig(world_size=N, tp_size=tp, overlap_chunks=4)
     torch.manual_seed(0)
     blocks = nn.ModuleList([_TPBlock(d, H, I, cfg) for _ in range(L)]).to(device="cuda", dtype=dt).eval()
     with torch.no_grad():
@@ -53,7 +56,8 @@ def bench_tp(N, B, S, d, H, I, L, dt, steps=3, warmup=1):
                 if isinstance(b, torch.Tensor):
                     b.zero_()
     x = torch.randn(B, S, d, device="cuda", dtype=dt)
-    dist.broadcast(x, 0)
+    grp = cfg.get_tp_group()
+    dist.broadcast(x, dist.get_global_rank(grp, 0) if grp is not None else 0, group=grp)  # one batch per tp group
 
     def fwd():
         y = x
@@ -74,8 +78,11 @@ def bench_tp(N, B, S, d, H, I, L, dt, steps=3, warmup=1):
             _sync()
             el = _max_over_ranks(time.perf_counter() - t0)
         key = "overlapped" if chunks > 1 else "unoverlapped"
-        out[key] = {"ms_per_step": el / steps * 1e3, "tokens_per_s": B * S * steps / el, "allreduce_chunks": chunks}
-    out["config"] = f"tp={N} global_batch={B} seq={S} d={d} h={H} L={L} (strong scaling of the 1-GPU workload)"
+        out[key] = {"ms_per_step": el / steps * 1e3, "tokens_per_s": (N // tp) * B * S * steps / el,
+                    "allreduce_chunks": chunks}
+    out["allreduce_payload_MiB_per_layer"] = 2 * B * S * d * 2 / 2 ** 20
+    out["config"] = (f"tp={tp} x dp={N // tp}: batch {B} per tp group, seq={S} d={d} h={H} L={L} "
+                     f"(strong scaling of the 1-GPU workload inside each group)")
     del blocks
     torch.cuda.empty_cache()
     return out
@@ -90,17 +97,23 @@ def bench_ring(N, S_total, d, H, dt, steps=3, warmup=1):
     torch.manual_seed(100 + dist.get_rank())
     q, k, v = (torch.randn(1, H, Sl, D, device="cuda", dtype=dt) for _ in range(3))
     out = {}
-    for name, kw in (("noncausal_mesh", dict(exchange="mesh")), ("noncausal_ring", dict(exchange="ring")),
+    pool = {}
+    for name, kw in (("noncausal_mesh", dict(exchange="mesh")),
+                     ("noncausal_mesh_unoverlapped", dict(exchange="mesh", overlap=False)),
+                     ("noncausal_ring", dict(exchange="ring")),
+                     ("noncausal_ring_unoverlapped", dict(exchange="ring", overlap=False)),
                      ("causal_zigzag_mesh", dict(exchange="mesh", causal=True, zigzag=True))):
         for _ in range(warmup):
-            ring_attention(q, k, v, None, layout="bhsd", **kw)
+            ring_attention(q, k, v, None, layout="bhsd", recv_buffers=pool, **kw)
         _sync()
         t0 = time.perf_counter()
         for _ in range(steps):
-            ring_attention(q, k, v, None, layout="bhsd", **kw)
+            ring_attention(q, k, v, None, layout="bhsd", recv_buffers=pool, **kw)
         _sync()
         el = _max_over_ranks(time.perf_counter() - t0) / steps
         flops = 4.0 * S_total * S_total * d * (0.5 if "causal" in kw else 1.0)
         out[name] = {"ms": el * 1e3, "tokens_per_s": S_total / el, "tflops_total": flops / el / 1e12}
-    out["config"] = f"sp={N} seq={S_total} d={d} h={H} B=1 attention core (q/k/v resident per rank)"
+    out["exchange_payload_MiB_per_step_per_rank"] = 2 * Sl * d * 2 / 2 ** 20
+    out["config"] = (f"sp={N} seq={S_total} d={d} h={H} B=1 attention core, q/k/v shards [1,{H},{Sl},{D}] resident per rank "
+                     f"(reference sequence_parallel.py:519-585 ring_exchange call site)")
     return out

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 import os, sys, torch
+os.environ.setdefault("MIO_LIB_DBG", "1")  # A/B switches and stamp kernels live in libmio_hip_dbg.so (make dbg)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ml-inference-optimizer_amd"))
 from mio import ops

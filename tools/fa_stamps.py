@@ -2,6 +2,7 @@
 """In-kernel phase stamps of fa3_fwd3_kernel (MIO_FA_DBG_PTR + MIO_FA_IMPL=3): cycles per KV tile spent in the DMA
 issue, phase 1 (QK^T || exp), phase 2 (PV || max), the reference update and the wait + barrier."""
 import os, sys
+os.environ.setdefault("MIO_LIB_DBG", "1")  # A/B switches and stamp kernels live in libmio_hip_dbg.so (make dbg)
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ml-inference-optimizer_amd"))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Fixed cost vs per-K-tile cost of the GEMM kernels: M=N=4096 (one 256x256 tile per CU), K swept."""
 import os, sys
+os.environ.setdefault("MIO_LIB_DBG", "1")  # A/B switches and stamp kernels live in libmio_hip_dbg.so (make dbg)
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ml-inference-optimizer_amd"))

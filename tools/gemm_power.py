@@ -3,6 +3,7 @@
 of launches are queued).  Tells a power-limited kernel (clock sinks as the schedule gets denser, time does not
 move) from an issue-limited one.   MIO_AB_SCALE=0 -> zero operands;  MIO_PW_LIB=1 -> torch.matmul (hipBLASLt)."""
 import os, subprocess, sys, time
+os.environ.setdefault("MIO_LIB_DBG", "1")  # A/B switches and stamp kernels live in libmio_hip_dbg.so (make dbg)
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ml-inference-optimizer_amd"))

@@ -2,6 +2,7 @@
 """In-kernel stamps of the 4-wave GEMM (diagnostic build path, MIO_GEMM_DBG_PTR): per-wave prologue / loop /
 epilogue cycles and the in-kernel clock (s_memtime / s_memrealtime)."""
 import os, sys
+os.environ.setdefault("MIO_LIB_DBG", "1")  # A/B switches and stamp kernels live in libmio_hip_dbg.so (make dbg)
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ml-inference-optimizer_amd"))

@@ -2,6 +2,7 @@
 """In-kernel stamps of the persistent GEMM (MIO_GEMM_DBG_PTR): per (tile, wave) prologue / K loop / read-out
 cycles after `sustain` launches, i.e. at the clock the chip holds under sustained load."""
 import os, sys
+os.environ.setdefault("MIO_LIB_DBG", "1")  # A/B switches and stamp kernels live in libmio_hip_dbg.so (make dbg)
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ml-inference-optimizer_amd"))
