@@ -310,7 +310,12 @@ def ring_exchange(*tensors: torch.Tensor, group: Optional[dist.ProcessGroup] = N
     out = recv
 
     class _Handle:
+        _done = False
+
         def wait(self_inner):
+            if self_inner._done:  # a work is waited for once: gloo blocks on a second wait
+                return
+            self_inner._done = True
             for w in works:
                 w.wait()
             if use_fp16:
