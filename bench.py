@@ -131,7 +131,7 @@ def kernel_rooflines(model, x, iters=10):
     o3, o1 = torch.empty_like(qkv), torch.empty_like(att)
     out = {}
     t = _events_ms(lambda: ops.fa3_fwd(q, k, v, causal=True), iters)
-    out["fa3_fwd3_kernel<bf16,causal>"] = dict(ms=t, launches=1, flops=2.0 * B * S * (S + 1) * d)
+    out["fa3_fwd4_kernel<bf16,causal>"] = dict(ms=t, launches=1, flops=2.0 * B * S * (S + 1) * d)
 
     t = _events_ms(lambda: ops.gemm_bias_act(ln1, wqkv, bqkv, out=o3, w_blocked=wqkv_b), iters)
     out["gemm4w16p_kernel<bf16,none>"] = dict(ms=t, launches=1, flops=2.0 * M * d * 3 * d)  # qkv

@@ -11,3 +11,12 @@ int mio_fail(const std::string& msg) {
 
 extern "C" int mio_version(void) { return MIO_VERSION; }
 extern "C" const char* mio_last_error(void) { return g_mio_err.c_str(); }
+
+#ifdef MIO_DIAG
+#include <atomic>
+static std::atomic<int> g_mio_dbg[8];
+extern "C" void mio_dbg_set(int key, int value) {
+  if (key >= 0 && key < 8) g_mio_dbg[key].store(value);
+}
+extern "C" int mio_dbg_get(int key) { return (key >= 0 && key < 8) ? g_mio_dbg[key].load() : 0; }
+#endif

@@ -120,7 +120,10 @@ struct Fa3P2Role {
   static_assert(count(1, 17) == 16 && count(32, 32 + UPW) == UPW, "phase 2: not every scale/max group or DMA unit has a step");
 };
 
-template <typename T, int D, bool CAUSAL, bool STAMP = false>
+// ABL (diagnostic build only, timing-only ablations with WRONG results -- what each piece of the tile loop costs):
+//   1 no scale-and-subtract / max in phase 2     2 no exp (P = converted S)     4 no row-sum MFMAs
+//   8 no DMA issue in the tile loop              16 no reference test / update  32 no edge masks
+template <typename T, int D, bool CAUSAL, bool STAMP = false, int ABL = 0>
 __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
   using X8 = typename DT<T>::x8;
   using X4 = typename DT<T>::x4;
@@ -422,10 +425,11 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
           if constexpr (hu != hu_prev) {
             constexpr int u = hu >> 1, half = hu & 1, qt = u >> 2, s = u & 3;
             constexpr int base = 8 * (s & 1) + 4 * half;
-            const float e0 = fast_exp2(S[cb][qt][s >> 1][base + 0]);
-            const float e1 = fast_exp2(S[cb][qt][s >> 1][base + 1]);
-            const float e2 = fast_exp2(S[cb][qt][s >> 1][base + 2]);
-            const float e3 = fast_exp2(S[cb][qt][s >> 1][base + 3]);
+            auto ex = [](float x) { return (ABL & 2) ? x : fast_exp2(x); };
+            const float e0 = ex(S[cb][qt][s >> 1][base + 0]);
+            const float e1 = ex(S[cb][qt][s >> 1][base + 1]);
+            const float e2 = ex(S[cb][qt][s >> 1][base + 2]);
+            const float e3 = ex(S[cb][qt][s >> 1][base + 3]);
             const uint32_t w0 = pack2<T>(e0, e1), w1 = pack2<T>(e2, e3);
             asm volatile("" ::"v"(w0), "v"(w1));  // a use in THIS block: keeps the exp / cvt work from sinking to phase 2
             pfw[qt][s][2 * half + 0] = w0;
@@ -476,16 +480,16 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
             constexpr int dt = m >> 1, qt = m & 1;
             Fa2Acc<T, FA3_T_O + qt * DT_ + dt>::mfma(vfr[s & 1][dt], __builtin_bit_cast(X8, pfw[qt][s]));
           } else if constexpr (m == 2 * DT_) {
-            OPS::template lsum0<FA3_A_ONES>(__builtin_bit_cast(X8, pfw[0][s]));
+            if constexpr (!(ABL & 4)) OPS::template lsum0<FA3_A_ONES>(__builtin_bit_cast(X8, pfw[0][s]));
           } else {
-            OPS::template lsum1<FA3_A_ONES>(__builtin_bit_cast(X8, pfw[1][s]));
+            if constexpr (!(ABL & 4)) OPS::template lsum1<FA3_A_ONES>(__builtin_bit_cast(X8, pfw[1][s]));
           }
           if constexpr (m == 1 && s + 1 < 4) read_v(vb, IC(s + 1));  // slot (s+1)&1 was last read by k-step s-1
-          if constexpr (ROLE::role(j) >= 32) dma_unit(IC(ROLE::role(j) - 32), dma_tile);
+          if constexpr (ROLE::role(j) >= 32 && !(ABL & 8)) dma_unit(IC(ROLE::role(j) - 32), dma_tile);
         }
         // scale-and-subtract + max of 4 scores per group, in the order the QK^T MFMAs of phase 1 finished writing
         // them: sub-tile qt = i / 8, 32-key half tt = (i / 4) & 1, registers 4 (i & 3) .. +3
-        if constexpr (ROLE::role(j) >= 1 && ROLE::role(j) <= 16) {
+        if constexpr (ROLE::role(j) >= 1 && ROLE::role(j) <= 16 && !(DO_PV && (ABL & 1))) {
           constexpr int i = ROLE::role(j) - 1, qt = i / 8, tt = (i / 4) & 1, r0 = 4 * (i & 3);
           // scalar fmas: this translation unit is compiled with -fno-slp-vectorize -- SLP packs adjacent scalar fmas into
           // v_pk_fma_f32, which costs more issue time beside MFMAs than the two scalar forms (MI355X_MICROARCH.md,
@@ -586,13 +590,15 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       const bool has_next = (t + 1 < n_w);
       phase1(CB_, IC(1), kb_n, vb_c);
       if constexpr (STAMP) c2 = __builtin_amdgcn_s_memtime();
-      if (has_next && is_edge(t + 1)) mask_tile(IC(cb ^ 1), (t + 1) * FA_BN);
+      if constexpr (!(ABL & 32))
+        if (has_next && is_edge(t + 1)) mask_tile(IC(cb ^ 1), (t + 1) * FA_BN);
       // (P words written by the vector ALU late in phase 1 are first read by an MFMA many steps into phase 2)
       if constexpr (STAMP) c2b = __builtin_amdgcn_s_memtime();
       dma_tile_base(t + 3);
       phase2(IC(cb ^ 1), IC(1), vb_c, t + 3);
       if constexpr (STAMP) c3 = __builtin_amdgcn_s_memtime();
-      if (has_next) update(IC(cb ^ 1));
+      if constexpr (!(ABL & 16))
+        if (has_next) update(IC(cb ^ 1));
       if constexpr (STAMP) c4 = __builtin_amdgcn_s_memtime();
       land();
       if constexpr (STAMP) {

@@ -6,6 +6,9 @@
 
 #include "fa3_fwd2_kernel.h"
 #include "fa3_fwd3_kernel.h"
+#if FA_D == 64
+#include "fa3_fwd4_kernel.h"
+#endif
 
 #if FA_TYPE_ID == 0
 using FaT = __bf16;
@@ -64,6 +67,31 @@ static int launch_three(FaDev p, hipStream_t stream) {
   const size_t smem = FA3_STAGES * FaSmem<FA_D>::STAGE;
   auto kern = fa3_fwd3_kernel<FaT, FA_D, CAUSAL>;
 #ifdef MIO_DIAG
+#if FA_D == 64 && FA_TYPE_ID == 0
+  if constexpr (CAUSAL) {  // timing-only ablations (tools/fa_ablate.py): mio_dbg_set(0, bits)
+    void (*ka)(const FaDev) = nullptr;
+    switch (mio_dbg_get(0)) {
+      case 1: ka = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, false, 1>; break;
+      case 2: ka = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, false, 2>; break;
+      case 3: ka = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, false, 3>; break;
+      case 4: ka = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, false, 4>; break;
+      case 8: ka = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, false, 8>; break;
+      case 16: ka = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, false, 16>; break;
+      case 32: ka = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, false, 32>; break;
+      case 48: ka = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, false, 48>; break;
+      case 57: ka = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, false, 57>; break;
+      case 59: ka = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, false, 59>; break;
+      case 63: ka = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, false, 63>; break;
+      default: break;
+    }
+    if (ka != nullptr) {
+      hipError_t ed = hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (ed != hipSuccess) return mio_fail(std::string("fa3_fwd3 (ablation): hipFuncSetAttribute: ") + hipGetErrorString(ed));
+      hipLaunchKernelGGL(ka, dim3(grid), dim3(256), smem, stream, p);
+      return 0;
+    }
+  }
+#endif
   static const char* dbg_ptr = std::getenv("MIO_FA_DBG_PTR");  // in-kernel phase stamps (tools/fa_stamps.py)
   if (dbg_ptr != nullptr) {
     auto kd = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, true>;
@@ -88,6 +116,49 @@ static int launch_three(FaDev p, hipStream_t stream) {
   return 0;
 }
 
+// fourth structure (two waves per SIMD, 8 waves x 32 query rows): head dim <= 64, no user mask, plain output
+#if FA_D == 64
+template <bool CAUSAL>
+static int launch_four(FaDev p, hipStream_t stream) {
+  p.nqblk = (p.Sq + FA4_BM - 1) / FA4_BM;
+  p.qgrid = CAUSAL ? (p.nqblk + 1) / 2 : p.nqblk;
+  const int grid = p.qgrid * p.B * p.H;
+  void (*kern)(const FaDev) = fa3_fwd4_kernel<FaT, CAUSAL>;
+#if defined(MIO_DIAG) && FA_TYPE_ID == 0
+  if constexpr (CAUSAL) {  // timing-only ablations (tools/fa4_ablate.py)
+    void (*ka)(const FaDev) = nullptr;
+    switch (mio_dbg_get(0)) {
+      case 1: ka = fa3_fwd4_kernel<FaT, CAUSAL, 1>; break;
+      case 2: ka = fa3_fwd4_kernel<FaT, CAUSAL, 2>; break;
+      case 4: ka = fa3_fwd4_kernel<FaT, CAUSAL, 4>; break;
+      case 8: ka = fa3_fwd4_kernel<FaT, CAUSAL, 8>; break;
+      case 12: ka = fa3_fwd4_kernel<FaT, CAUSAL, 12>; break;
+      case 16: ka = fa3_fwd4_kernel<FaT, CAUSAL, 16>; break;
+      case 32: ka = fa3_fwd4_kernel<FaT, CAUSAL, 32>; break;
+      case 35: ka = fa3_fwd4_kernel<FaT, CAUSAL, 35>; break;
+      case 47: ka = fa3_fwd4_kernel<FaT, CAUSAL, 47>; break;
+      case 64: ka = fa3_fwd4_kernel<FaT, CAUSAL, 64>; break;
+      default: break;
+    }
+    if (ka != nullptr) {
+      hipError_t ed = hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, FA4_SMEM);
+      if (ed != hipSuccess) return mio_fail(std::string("fa3_fwd4 (ablation): hipFuncSetAttribute: ") + hipGetErrorString(ed));
+      hipLaunchKernelGGL(ka, dim3(grid), dim3(512), FA4_SMEM, stream, p);
+      return 0;
+    }
+  }
+#endif
+  static std::once_flag once;
+  static hipError_t ea = hipSuccess;
+  std::call_once(once, [&] { ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, FA4_SMEM); });
+  if (ea != hipSuccess) return mio_fail(std::string("fa3_fwd4: hipFuncSetAttribute: ") + hipGetErrorString(ea));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), FA4_SMEM, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("fa3_fwd4 launch: ") + hipGetErrorString(e));
+  return 0;
+}
+#endif
+
 #ifdef MIO_DIAG
 static int fa_impl() {  // MIO_FA_IMPL=1 / 2 / 3 force one structure for A/B runs (0 = the rule in fa3_launch)
   static const int v = [] {
@@ -109,6 +180,23 @@ int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t
   //   user masks and Sq <= 128: the two-waves-per-SIMD kernel.
   // (the pipelined kernel addresses K / V tiles with 32-bit byte offsets from the (batch, head) base)
   const bool span32 = (int64_t)p.Sk * p.ks_s * 2 < (1ll << 32) && (int64_t)p.Sk * p.vs_s * 2 < (1ll << 32);
+#if FA_D == 64
+  // head dim <= 64, causal, plain output: the two-waves-per-SIMD kernel (0.325 vs 0.336 ms at B8 S4096 H16 interleaved on
+  // one box; non-causal it is 1 % behind fa3_fwd3 and stays there).  Diagnostic build: MIO_FA_IMPL=3 / mio_dbg_set(1, 3)
+  // keep fa3_fwd3, = 4 force fa3_fwd4 for non-causal launches too.
+  {
+    const bool plain = mask_kind == MIO_MASK_NONE && p.Sq > 128 && span32 && p.o != nullptr && p.o_acc == nullptr && !p.carry_in;
+    bool four = plain && causal && fa_impl() == 0;
+#ifdef MIO_DIAG
+    if (mio_dbg_get(1) == 3) four = false;
+    if (plain && (fa_impl() == 4 || mio_dbg_get(1) == 4)) four = true;
+#endif
+    if (four && causal) return launch_four<true>(p, stream);
+#ifdef MIO_DIAG
+    if (four) return launch_four<false>(p, stream);
+#endif
+  }
+#endif
   if ((fa_impl() == 3 || fa_impl() == 0) && mask_kind == MIO_MASK_NONE && p.Sq > 128 && span32)
     return causal ? launch_three<true>(p, stream) : launch_three<false>(p, stream);
 #ifdef MIO_DIAG

@@ -98,4 +98,10 @@ int mio_fail(const std::string& msg);  // sets the message, returns -1
     if (e__ != hipSuccess) return mio_fail(std::string(#expr) + ": " + hipGetErrorString(e__)); \
   } while (0)
 
+#ifdef MIO_DIAG
+// diagnostic build only (libmio_hip_dbg.so): integer knobs the tools set between launches of one process
+extern "C" void mio_dbg_set(int key, int value);
+extern "C" int mio_dbg_get(int key);
+#endif
+
 static inline bool mio_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

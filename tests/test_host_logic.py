@@ -293,6 +293,30 @@ def test_fwd3_accumulator_registers_untouched_by_compiler(tmp_path, type_id, D):
         assert not any("scratch_" in l for l in text[a:b + 1]), "register spills in " + text[a]
 
 
+def test_fwd4_two_waves_per_simd_fits_without_spills(tmp_path):
+    """fa3_fwd4_kernel runs two waves per SIMD: 256 registers per wave.  It must fit them without scratch (a staggered
+    variant that did not fit ran 60 % slower) -- check the ISA metadata of both dtypes' causal instantiation."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "ml-inference-optimizer_amd", "csrc")
+    for type_id in (0, 1):
+        isa = tmp_path / f"fa{type_id}.s"
+        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I../../include", "-I.", "-Wno-unused-value",
+                        "-Wno-inline-asm", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize", f"-DFA_TYPE_ID={type_id}",
+                        "-DFA_D=64", "-S", "--cuda-device-only", "fa3_fwd_inst.hip", "-o", str(isa)], cwd=csrc, check=True,
+                       capture_output=True)
+        text = isa.read_text()
+        blocks = re.findall(r"\.name:\s+_Z15fa3_fwd4_kernel\w+\n(?:.*\n){0,12}", text)
+        assert blocks, "fa3_fwd4_kernel is not instantiated in the product build"
+        for blk in blocks:
+            assert re.search(r"\.private_segment_fixed_size:\s+0\b", blk), blk
+            assert re.search(r"\.vgpr_spill_count:\s+0\b", blk), blk
+            assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 256, blk
+
+
 @pytest.mark.parametrize("D", [64, 96, 128])
 def test_fwd2_accumulator_registers_untouched_by_compiler(tmp_path, D):
     """fa3_fwd2_kernel keeps its 2*D/32 O^T tiles in the top accumulator registers a[256 - 32*D/32*... : 255] through

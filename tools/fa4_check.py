@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""fa3_fwd4_kernel (two waves per SIMD) against fa3_fwd3_kernel and an fp32 torch reference, then interleaved A/B timing
+at the benchmark shape (diagnostic build: mio_dbg_set(1, 4) routes eligible launches to fwd4)."""
+import os, sys
+os.environ.setdefault("MIO_LIB_DBG", "1")
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-inference-optimizer_amd")]
+from mio import ops, _lib
+dev = "cuda"
+def ref_attn(q, k, v, causal, q_off=0, k_off=0):
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))
+    if k.shape[2] != H:
+        rep = H // k.shape[2]
+        kf, vf = kf.repeat_interleave(rep, 1), vf.repeat_interleave(rep, 1)
+    s = (qf @ kf.transpose(-1, -2)) / D ** 0.5
+    if causal:
+        qi = torch.arange(Sq, device=dev)[:, None] + q_off
+        ki = torch.arange(Sk, device=dev)[None, :] + k_off
+        s = s.masked_fill(ki > qi, float("-inf"))
+    lse = torch.logsumexp(s, -1)
+    pr = torch.exp(s - torch.where(torch.isinf(lse), torch.zeros_like(lse), lse)[..., None])
+    pr = torch.where(torch.isinf(lse)[..., None], torch.zeros_like(pr), pr)
+    return (pr @ vf).permute(0, 2, 1, 3), lse
+bad = 0
+cases = [(1, 300, 300, 4, 4, 64, False, 0, 0), (2, 300, 300, 4, 4, 64, True, 0, 0), (1, 129, 1, 6, 2, 64, False, 0, 0),
+         (1, 257, 130, 6, 2, 64, False, 0, 0), (1, 511, 511, 6, 2, 64, True, 0, 0), (1, 256, 192, 6, 2, 64, True, 64, 128),
+         (1, 200, 200, 6, 2, 64, True, 0, 200), (1, 130, 300, 6, 2, 64, True, 170, 0), (1, 192, 192, 3, 3, 32, True, 0, 0),
+         (1, 1024, 1024, 8, 8, 64, True, 0, 0), (1, 4096, 4096, 8, 8, 64, True, 0, 0), (1, 4096, 4096, 8, 8, 64, False, 0, 0),
+         (1, 2048, 2048, 8, 8, 48, True, 0, 0)]
+for dtype in (torch.bfloat16, torch.float16):
+    for (B, Sq, Sk, H, Hkv, D, causal, qo, ko) in cases:
+        torch.manual_seed(Sq + Sk)
+        q = (torch.randn(B, Sq, H, D, device=dev) * (3 if Sq >= 4096 else 1)).to(dtype)
+        k = torch.randn(B, Sk, Hkv, D, device=dev).to(dtype)
+        v = torch.randn(B, Sk, Hkv, D, device=dev).to(dtype)
+        _lib.lib.mio_dbg_set(1, 4)
+        o4, l4 = ops.fa3_fwd(q, k, v, causal=causal, q_offset=qo, k_offset=ko, return_lse=True)
+        _lib.lib.mio_dbg_set(1, 3)
+        o3, l3 = ops.fa3_fwd(q, k, v, causal=causal, q_offset=qo, k_offset=ko, return_lse=True)
+        ro, rl = ref_attn(q, k, v, causal, qo, ko)
+        empty = torch.isinf(rl)
+        ok_inf = torch.equal(torch.isinf(l4), empty)
+        keep = (~empty).permute(0, 2, 1)[..., None].expand_as(ro)
+        def rel(o):
+            if not keep.any(): return 0.0
+            return ((o.float()[keep] - ro[keep]).abs().mean() / ro[keep].abs().mean()).item()
+        r4, r3 = rel(o4), rel(o3)
+        dl = (l4 - rl)[~empty].abs().max().item() if (~empty).any() else 0.0
+        z = (o4.float()[~keep] == 0).all().item() if (~keep).any() else True
+        tol = 3e-3 if dtype == torch.bfloat16 else 1e-3
+        good = ok_inf and r4 < tol and dl < (6e-3 if dtype == torch.bfloat16 else 2e-3) and z
+        bad += 0 if good else 1
+        print(f"{str(dtype)[6:]:9s} B{B} Sq{Sq} Sk{Sk} H{H}/{Hkv} D{D} causal={int(causal)} off=({qo},{ko}): fwd4 rel {r4:.2e} lse {dl:.1e} | fwd3 rel {r3:.2e} {'ok' if good else 'FAIL'}", flush=True)
+print("FAILURES:", bad, flush=True)
+# ---- timing
+B, S, H, D = 8, 4096, 16, 64
+torch.manual_seed(0)
+q, k, v = (torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16) for _ in range(3))
+o = torch.empty_like(q)
+def run(n, causal):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        ops.fa3_fwd(q, k, v, causal=causal, out=o)
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+VAR = int(os.environ.get("FA4_VAR", "0"))  # fwd4 variant (mio_dbg_set(0, VAR)); e.g. 64 = row sums on the vector ALU
+def sel(impl):
+    _lib.lib.mio_dbg_set(1, 4 if impl >= 4 else 3)
+    _lib.lib.mio_dbg_set(0, VAR if impl == 5 else 0)
+for causal in (True, False):
+    impls = (3, 4, 5) if (VAR and causal) else (3, 4)
+    res = {i: [] for i in impls}
+    for impl in impls:
+        sel(impl); run(200, causal)
+    for _ in range(5):
+        for impl in impls:
+            sel(impl); run(50, causal); res[impl].append(run(200, causal))
+    fl = (2.0 * B * S * (S + 1) * H * D) if causal else 4.0 * B * S * S * H * D
+    for impl in impls:
+        t = min(res[impl])
+        print(f"causal={int(causal)} fwd{impl if impl < 5 else '4/var' + str(VAR)}: min {t:.4f} ms  {fl / t / 1e9:.0f} TFLOP/s  frac {fl / t / 1e9 / 2500:.3f}", flush=True)
+if VAR:  # the variant's values (causal bf16 only is instantiated)
+    _lib.lib.mio_dbg_set(1, 4); _lib.lib.mio_dbg_set(0, VAR)
+    o5, l5 = ops.fa3_fwd(q, k, v, causal=True, return_lse=True)
+    _lib.lib.mio_dbg_set(0, 0)
+    o4, l4 = ops.fa3_fwd(q, k, v, causal=True, return_lse=True)
+    print("variant vs fwd4: max|do|", (o5.float() - o4.float()).abs().max().item(), "max|dlse|", (l5 - l4).abs().max().item(), flush=True)
