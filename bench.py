@@ -164,7 +164,7 @@ def decode_leg(dt):
     nbytes = 2.0 * Bd * ctx * Hd * Dd * 2
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {"workload": f"paged decode q_len 1, B {Bd} H {Hd} D {Dd} ctx {ctx} block {bs} (random physical blocks)",
-            "kernel": "decode_paged_kernel + decode_reduce_kernel", "bound": "hbm", "ms": ms, "achieved": gbs,
+            "kernel": "decode_rows_kernel + decode_reduce_kernel", "bound": "hbm", "ms": ms, "achieved": gbs,
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "bytes_per_launch": nbytes,
             "tokens_per_s": Bd / (ms * 1e-3)}
 

@@ -43,6 +43,30 @@ static inline int dec_nsplit(int B, int H, int q_len, int max_ctx) {
   return want;
 }
 
+// whole-token-row kernel (decode_rows_kernel): one workgroup per (sequence, split) -> the split count aims at the same
+// number of workgroups with B sequences instead of B * H * q_len rows
+static inline int dec_nsplit_rows(int B, int max_ctx) {
+  int target = 512;  // workgroups aimed for: 2 per CU (sweep 256 .. 4096 at B 8 / 32 / 64 / 256: tools/dbg/dec_rows_sweep.py)
+#ifdef MIO_DIAG
+  if (mio_dbg_get(2) > 0) target = mio_dbg_get(2);  // tuning sweep (tools/dbg/dec_rows_sweep.py)
+#endif
+  int want = (target + B - 1) / B;
+  int cap = (max_ctx + 63) / 64;
+  if (cap < 1) cap = 1;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  return want;
+}
+// Picked for B >= 16: at B 8 (128 MiB of cache, Infinity-Cache resident between launches) the per-head kernel's 512
+// small workgroups run 28 us against 40-46 us here; from B 32 on (streams from HBM) the whole-row reads win:
+// B 64 H 16 D 64 187 -> 183 us (5.87 TB/s), B 256 6.06 TB/s (tools/dbg/dec_rows_sweep.py).
+static inline bool dec_rows_ok(int B, int H, int Hkv, int q_len, int D) {
+  if (B < 16) return false;
+  if (D != 64 && D != 128) return false;
+  const int cpt = Hkv * (D / 8), qn = (H / Hkv) * q_len;
+  return cpt >= 16 && cpt <= 256 && (cpt & (cpt - 1)) == 0 && (qn == 1 || qn == 2 || qn == 4);
+}
+
 // CPRP = chunks-per-row padded to a power of two (8 for D <= 64, 16 for D <= 128)
 template <typename T, int CPRP, int U>
 __global__ __launch_bounds__(256) void decode_paged_kernel(const DecDev p) {
@@ -202,6 +226,189 @@ __global__ __launch_bounds__(256) void decode_paged_kernel(const DecDev p) {
   }
 }
 
+// ---- whole-token-row variant -------------------------------------------------------------------------------------------
+// decode_paged_kernel reads 128- / 256-byte pieces (one head of one token) at the token stride Hkv * D * 2 bytes: every
+// piece is a separate HBM burst in a random physical block, and the other heads' workgroups fetch the neighbouring pieces
+// at other times (5.1-5.4 TB/s at B 64, H 16, D 64).  Here ONE workgroup owns a (sequence, context split) for ALL heads:
+// a wave-load is 64 lanes x 16 B = 1 KiB of ONE token row (contiguous: the cache stores [token][Hkv][D]), a lane keeps the
+// running softmax state of its own (kv head, 16-byte chunk) for the QN = (H / Hkv) * q_len query vectors that attend
+// through that kv head, and consecutive tokens of a block are consecutive 2-KiB rows -- 32 KiB contiguous per block.
+//   CPR  = chunks per head row (D / 8: 8 or 16)          CPT = Hkv * CPR chunks per token row (16 .. 256, power of two)
+//   CPT >= 64: the row is NPART = CPT / 64 wave-loads; wave w takes part w % NPART of tokens (w / NPART) + k * (4 / NPART)
+//   CPT <  64: one wave-load holds TPL = 64 / CPT tokens; wave w takes token slots 4 k + w
+// Same clamped-address / masked-score loop as decode_paged_kernel, batches of U token slots, double-buffered.
+template <typename T, int CPR, int QN>
+__global__ __launch_bounds__(256) void decode_rows_kernel(const DecDev p) {
+  constexpr int U = 2;  // token slots per batch (U = 4 measured the same within 2 %)
+  __shared__ float s_st[4][64][QN][10];  // per (wave, lane, query): o[8], m, l
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, split = blockIdx.y;
+  const int CPT = p.Hkv * CPR;
+  const int npart = CPT >= 64 ? CPT / 64 : 1;
+  const int tpl = CPT >= 64 ? 1 : 64 / CPT;             // tokens per wave-load
+  const int part = wave % npart, tslot = wave / npart;  // this wave's slice of the row / token slot
+  const int wpp = 4 / npart;                            // waves per part
+  const int tl = CPT >= 64 ? 0 : lane / CPT;            // token inside the wave-load
+  const int cidx = CPT >= 64 ? part * 64 + lane : lane % CPT;  // 16-byte chunk of the token row
+  const int kvh = cidx / CPR, c = cidx % CPR;
+  const int rep = p.H / p.Hkv;
+  const int ctx = p.cl[b];
+  const int begin = split * p.split_len;
+  int end = begin + p.split_len;
+  if (end > ctx) end = ctx;
+
+  float qf[QN][8];
+#pragma unroll
+  for (int j = 0; j < QN; ++j) {
+    const int h = kvh * rep + j / p.q_len, qi = j % p.q_len;
+    const u32x4_t raw = *(const u32x4_t*)((const T*)p.q + b * p.qs_b + h * p.qs_h + (int64_t)qi * p.qs_s + 8 * c);
+    const typename DT<T>::x8 v = __builtin_bit_cast(typename DT<T>::x8, raw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qf[j][i] = (float)v[i] * p.scale;
+  }
+  float m[QN], l[QN], o[QN][8];
+#pragma unroll
+  for (int j = 0; j < QN; ++j) {
+    m[j] = -INFINITY;
+    l[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[j][i] = 0.f;
+  }
+
+  const int64_t tok_stride = (int64_t)p.Hkv * p.D;
+  const int64_t blk_stride = (int64_t)p.L * p.bs * tok_stride;
+  const int64_t lay_off = (int64_t)p.layer * p.bs * tok_stride + (int64_t)cidx * 8;
+  const int32_t* btrow = p.bt + (int64_t)b * p.max_blocks;
+  const int step = wpp * tpl;  // tokens the workgroup covers per slot
+  const int last = end - 1;
+  auto tok = [&](int pos0, int j) { return pos0 + j * step + tl; };
+  auto load_pb = [&](int pos0, int (&pb)[U]) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int pos = min(tok(pos0, j), last);
+      pb[j] = btrow[min(pos / p.bs, p.max_blocks - 1)];
+    }
+  };
+  auto load_kv = [&](int pos0, const int (&pb)[U], u32x4_t (&kr)[U], u32x4_t (&vr)[U]) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int pos = min(tok(pos0, j), last);
+      const int64_t off = (int64_t)pb[j] * blk_stride + lay_off + (int64_t)(pos % p.bs) * tok_stride;
+      kr[j] = *(const u32x4_t*)((const T*)p.kc + off);
+      vr[j] = *(const u32x4_t*)((const T*)p.vc + off);
+    }
+  };
+  auto reduce = [&](int pos0, const u32x4_t (&kr)[U], const u32x4_t (&vr)[U]) {
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      float sc[U];
+      float m_new = m[q];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const typename DT<T>::x8 kv = __builtin_bit_cast(typename DT<T>::x8, kr[j]);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += qf[q][i] * (float)kv[i];
+#pragma unroll
+        for (int x = 1; x < CPR; x <<= 1) s += __shfl_xor(s, x, 64);
+        const int pos = tok(pos0, j);
+        sc[j] = (pos < end && pos / p.bs < p.max_blocks) ? s : -INFINITY;
+        m_new = fmaxf(m_new, sc[j]);
+      }
+      const float m_ref = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __expf(m[q] - m_ref);
+      l[q] *= alpha;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[q][i] *= alpha;
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const typename DT<T>::x8 vv = __builtin_bit_cast(typename DT<T>::x8, vr[j]);
+        const float pe = __expf(sc[j] - m_ref);
+        l[q] += pe;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[q][i] += pe * (float)vv[i];
+      }
+      m[q] = m_new;
+    }
+  };
+  {
+    const int BATCH = U * step;
+    int pbA[U], pbB[U], pbC[U];
+    u32x4_t kA[U], vA[U], kB[U], vB[U];
+    auto shift = [&]() {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        pbA[j] = pbB[j];
+        pbB[j] = pbC[j];
+      }
+    };
+    int pos0 = begin + tslot * tpl;
+    if (begin >= end) pos0 = end;  // empty split: no loads at all
+    else {
+      load_pb(pos0, pbA);
+      load_pb(pos0 + BATCH, pbB);
+      load_kv(pos0, pbA, kA, vA);
+    }
+    while (pos0 < end) {
+      load_pb(pos0 + 2 * BATCH, pbC);
+      load_kv(pos0 + BATCH, pbB, kB, vB);
+      reduce(pos0, kA, vA);
+      pos0 += BATCH;
+      if (pos0 >= end) break;
+      shift();
+      load_pb(pos0 + 2 * BATCH, pbC);
+      load_kv(pos0 + BATCH, pbB, kA, vA);
+      reduce(pos0, kB, vB);
+      pos0 += BATCH;
+      shift();
+    }
+  }
+  // ---- merge the states of one (chunk of the row, query) held by several waves / token slots
+#pragma unroll
+  for (int q = 0; q < QN; ++q) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_st[wave][lane][q][i] = o[q][i];
+    s_st[wave][lane][q][8] = m[q];
+    s_st[wave][lane][q][9] = l[q];
+  }
+  __syncthreads();
+  if (tslot == 0 && tl == 0) {  // one lane per chunk of the row: its own state first, then the others'
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      float M = -INFINITY;
+      for (int w = part; w < 4; w += npart)
+        for (int t2 = 0; t2 < tpl; ++t2) M = fmaxf(M, s_st[w][(CPT >= 64 ? lane : t2 * CPT + cidx)][q][8]);
+      float Ls = 0.f, acc[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+      if (M != -INFINITY) {
+        for (int w = part; w < 4; w += npart)
+          for (int t2 = 0; t2 < tpl; ++t2) {
+            const float* st = s_st[w][(CPT >= 64 ? lane : t2 * CPT + cidx)][q];
+            const float wgt = __expf(st[8] - M);
+            Ls += st[9] * wgt;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += st[i] * wgt;
+          }
+      }
+      const float inv = (Ls > 0.f) ? 1.f / Ls : 0.f;  // empty context -> 0 (attention_kernels.py:802)
+      const int h = kvh * rep + q / p.q_len, qi = q % p.q_len;
+      const int64_t row = ((int64_t)b * p.H + h) * p.q_len + qi;
+      if (p.nsplit == 1) {
+        T* op = (T*)p.o + b * p.os_b + h * p.os_h + (int64_t)qi * p.os_s + 8 * c;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) op[i] = (T)(acc[i] * inv);
+      } else {
+        float* wo = p.ws_o + (row * p.nsplit + split) * p.D + 8 * c;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wo[i] = acc[i] * inv;
+        if (c == 0) p.ws_lse[row * p.nsplit + split] = (Ls > 0.f) ? M + __logf(Ls) : -INFINITY;
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(128) void decode_reduce_kernel(const DecDev p) {
   const int row = blockIdx.x, d = threadIdx.x;
@@ -245,8 +452,22 @@ static void dec_launch(const DecDev& p, dim3 grid, hipStream_t st) {
   if (p.nsplit > 1) hipLaunchKernelGGL(decode_reduce_kernel<T>, dim3(grid.x), dim3(128), 0, st, p);
 }
 
+template <typename T>
+static void dec_launch_rows(const DecDev& p, int qn, unsigned rows, hipStream_t st) {
+  const dim3 grid((unsigned)p.B, (unsigned)p.nsplit);
+#define MIO_DEC_ROWS(CPR_, QN_) hipLaunchKernelGGL((decode_rows_kernel<T, CPR_, QN_>), grid, dim3(256), 0, st, p)
+  if (p.D == 64) {
+    if (qn == 1) MIO_DEC_ROWS(8, 1); else if (qn == 2) MIO_DEC_ROWS(8, 2); else MIO_DEC_ROWS(8, 4);
+  } else {
+    if (qn == 1) MIO_DEC_ROWS(16, 1); else if (qn == 2) MIO_DEC_ROWS(16, 2); else MIO_DEC_ROWS(16, 4);
+  }
+#undef MIO_DEC_ROWS
+  if (p.nsplit > 1) hipLaunchKernelGGL(decode_reduce_kernel<T>, dim3(rows), dim3(128), 0, st, p);
+}
+
 extern "C" size_t mio_fa3_decode_workspace_bytes(int32_t B, int32_t H, int32_t q_len, int32_t D, int32_t max_ctx) {
-  const int ns = dec_nsplit(B, H, q_len, max_ctx);
+  const int ns_a = dec_nsplit(B, H, q_len, max_ctx), ns_b = dec_nsplit_rows(B, max_ctx);
+  const int ns = ns_a > ns_b ? ns_a : ns_b;  // covers whichever kernel the launch picks (it does not know Hkv here)
   return (size_t)B * H * q_len * ns * (size_t)(D + 1) * sizeof(float) + 256;
 }
 
@@ -271,7 +492,8 @@ extern "C" int mio_fa3_decode_paged(const void* q, void* o, const void* k_cache,
   p.os_b = o_stride[0]; p.os_h = o_stride[1]; p.os_s = o_stride[2];
   p.B = B; p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.D = D; p.L = num_layers; p.layer = layer_idx;
   p.bs = block_size; p.max_blocks = max_blocks_per_seq; p.scale = scale;
-  p.nsplit = dec_nsplit(B, H, q_len, max_ctx);
+  const bool rows_kernel = dec_rows_ok(B, H, Hkv, q_len, D);
+  p.nsplit = rows_kernel ? dec_nsplit_rows(B, max_ctx) : dec_nsplit(B, H, q_len, max_ctx);
   int sl = (max_ctx + p.nsplit - 1) / p.nsplit;
   sl = (sl + 31) / 32 * 32;
   if (sl < 32) sl = 32;
@@ -282,7 +504,10 @@ extern "C" int mio_fa3_decode_paged(const void* q, void* o, const void* k_cache,
   p.ws_lse = p.ws_o ? p.ws_o + rows * p.nsplit * D : nullptr;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)rows, (unsigned)p.nsplit), block(256);
-  if (dtype == MIO_BF16) dec_launch<__bf16>(p, grid, st);
+  if (rows_kernel) {
+    if (dtype == MIO_BF16) dec_launch_rows<__bf16>(p, (H / Hkv) * q_len, (unsigned)rows, st);
+    else dec_launch_rows<_Float16>(p, (H / Hkv) * q_len, (unsigned)rows, st);
+  } else if (dtype == MIO_BF16) dec_launch<__bf16>(p, grid, st);
   else dec_launch<_Float16>(p, grid, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mio_fail(std::string("decode_paged launch: ") + hipGetErrorString(e));

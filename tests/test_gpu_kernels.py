@@ -426,15 +426,21 @@ def test_layernorm(golden_dir, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("D,H,Hkv,q_len", [(64, 4, 4, 1), (128, 8, 2, 1), (80, 2, 2, 3)])
+@pytest.mark.parametrize("D,H,Hkv,q_len", [
+    (64, 4, 4, 1), (128, 8, 2, 1), (80, 2, 2, 3),
+    # whole-token-row kernel geometries: row = 2 / 4 wave-loads (H 16: the bench.py decode leg), two query positions,
+    # a row of exactly one wave-load with two query heads per kv head
+    (64, 16, 16, 1), (128, 16, 16, 1), (64, 8, 8, 2), (64, 16, 8, 1),
+])
 def test_paged_decode_and_cache(dtype, D, H, Hkv, q_len):
     ops = _ops()
     torch.manual_seed(D + H)
-    B, bs, L, nblk, maxb = 3, 16, 2, 64, 20
-    ctx = torch.tensor([300, 17, 0], dtype=torch.int32)
+    B, bs, L, maxb = (3 if H < 8 else 18), 16, 2, 20   # B >= 16 takes the whole-token-row kernel where the geometry fits
+    nblk = B * maxb + 4
+    ctx = torch.tensor(([300, 17, 0] * 6)[:B], dtype=torch.int32)
     kc = torch.randn(nblk, L, bs, Hkv, D).to(dtype)
     vc = torch.randn(nblk, L, bs, Hkv, D).to(dtype)
-    bt = torch.stack([torch.randperm(nblk)[:maxb] for _ in range(B)]).to(torch.int32)
+    bt = torch.randperm(nblk)[:B * maxb].view(B, maxb).to(torch.int32)  # disjoint physical blocks per sequence
     q = torch.randn(B, H, q_len, D).to(dtype)
     out = torch.empty(B, H, q_len, D, dtype=dtype, device=DEV)
     kcd, vcd = kc.to(DEV), vc.to(DEV)
@@ -442,6 +448,10 @@ def test_paged_decode_and_cache(dtype, D, H, Hkv, q_len):
     ref = oracle.paged_attention_forward(q, kc, vc, bt, ctx, bs, 1)
     _cmp(out, ref, dtype, "paged")
     assert out[2].abs().max() == 0  # empty context -> zeros (attention_kernels.py:802)
+    if B > 3:
+        ctx[3:] = torch.tensor([319, 256, 1, 64, 129, 255, 318, 16, 15, 33, 100, 200, 7, 303, 48][:B - 3], dtype=torch.int32)
+        ops.paged_attention_forward(q.to(DEV), out, kcd, vcd, bt.to(DEV), ctx.to(DEV), bs, 320, 1)
+        _cmp(out, oracle.paged_attention_forward(q, kc, vc, bt, ctx, bs, 1), dtype, "paged ragged")
     # cache write for the next token, then decode again: must equal the oracle on the updated cache
     knew, vnew = torch.randn(B, 1, Hkv, D).to(dtype), torch.randn(B, 1, Hkv, D).to(dtype)
     ctx2 = ctx + 1
