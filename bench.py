@@ -121,19 +121,23 @@ def kernel_rooflines(model, x, iters=10):
     # weights in the blocked layout, as the modules hand them over at this size (mio/_nn.py linear)
     wqkv_b, wo_b, w1_b, w2_b = (ops.block_weight(t) for t in (wqkv, wo, w1, w2))
     ln1 = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
-    qkv = ops.gemm_bias_act(ln1, wqkv, bqkv)
+    # as FlashSelfAttention runs it: the QKV projection's epilogue scales the K columns by softmax_scale * log2(e) in fp32
+    # (one rounding) and the attention kernel is told so (k_prescaled) where both kernels support it
+    kpre = (D <= 64 and d % 128 == 0 and ops.col_scale_ok(M, 3 * d, d) and ops.fa3_k_prescaled_ok(B, S, S, H, D, 3 * d, 3 * d))
+    cs = (d, 2 * d, 1.4426950408889634 / D ** 0.5) if kpre else None
+    qkv = ops.gemm_bias_act(ln1, wqkv, bqkv, w_blocked=wqkv_b, col_scale=cs)
     q = qkv[:, :, :d].view(B, S, H, D)
     k = qkv[:, :, d:2 * d].view(B, S, H, D)
     v = qkv[:, :, 2 * d:].view(B, S, H, D)
-    ctx = ops.fa3_fwd(q, k, v, causal=True).view(B, S, d)
+    ctx = ops.fa3_fwd(q, k, v, causal=True, k_prescaled=kpre).view(B, S, d)
     att = ops.gemm_bias_act(ctx, wo, bo, residual=x)
     ln2 = ops.layernorm(att, blk.ln_2.weight, blk.ln_2.bias)
     o3, o1 = torch.empty_like(qkv), torch.empty_like(att)
     out = {}
-    t = _events_ms(lambda: ops.fa3_fwd(q, k, v, causal=True), iters)
-    out["fa3_fwd4_kernel<bf16,causal>"] = dict(ms=t, launches=1, flops=2.0 * B * S * (S + 1) * d)
+    t = _events_ms(lambda: ops.fa3_fwd(q, k, v, causal=True, k_prescaled=kpre), iters)
+    out["fa3_fwd4_kernel<bf16,causal" + (",k_prescaled>" if kpre else ">")] = dict(ms=t, launches=1, flops=2.0 * B * S * (S + 1) * d)
 
-    t = _events_ms(lambda: ops.gemm_bias_act(ln1, wqkv, bqkv, out=o3, w_blocked=wqkv_b), iters)
+    t = _events_ms(lambda: ops.gemm_bias_act(ln1, wqkv, bqkv, out=o3, w_blocked=wqkv_b, col_scale=cs), iters)
     out["gemm4w16p_kernel<bf16,none>"] = dict(ms=t, launches=1, flops=2.0 * M * d * 3 * d)  # qkv
     # the MLP as the model runs it: fc1 + GELU (persistent kernel) writes the blocked intermediate, fc2 + residual reads it
     t = _events_ms(lambda: ops.fused_mlp(ln2, w1, b1, w2, b2, "gelu", residual=att, fc1_blocked=w1_b, fc2_blocked=w2_b), iters)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MIO_VERSION 100 /* 0.1.0 */
+#define MIO_VERSION 101 /* 0.1.0 */
 
 typedef enum { MIO_BF16 = 0, MIO_FP16 = 1 } mio_dtype_t;
 
@@ -88,9 +88,15 @@ typedef struct {
   int32_t carry_in;  /* 0/1 */
   int32_t q_offset, k_offset;
   float softmax_scale; /* > 0 */
+  int32_t k_prescaled; /* 0/1: k already holds K * softmax_scale * log2(e), scaled in fp32 BEFORE its rounding to 16 bits
+                          (mio_gemm_bias_act_bw col_scale: the epilogue of the projection that produced it).  Only for
+                          launches mio_fa3_k_prescaled_ok() accepts; the kernel then skips the per-score multiply. */
 } mio_fa3_fwd_params_t;
 
 int mio_fa3_fwd(const mio_fa3_fwd_params_t* p, void* stream);
+/* 1 iff a launch with these parameters (k_prescaled ignored) may set k_prescaled = 1: head dim <= 64, no user mask, no
+ * (o_acc, lse) carry, Sq > 128, K / V rows within 4 GiB of their (batch, head) base. */
+int32_t mio_fa3_k_prescaled_ok(const mio_fa3_fwd_params_t* p);
 
 /* Merge two normalised partial attention states over disjoint key sets (ring / split-KV):
  * o = w_a*o_a + w_b*o_b, lse = logaddexp(lse_a, lse_b), w_x = exp(lse_x - lse).
@@ -140,6 +146,14 @@ int32_t mio_gemm_blocked_weight_ok(int64_t M, int32_t N, int32_t K, int32_t act)
 int mio_gemm_bias_act_bw(const void* x, const void* wb, const void* bias, const void* residual, void* y, int64_t M,
                          int32_t N, int32_t K, int64_t ldx, int64_t ldy, int64_t ldr, int32_t act, int32_t dtype,
                          int32_t x_blocked, void* stream);
+/* The same (no residual) with output columns [cs_lo, cs_hi) multiplied by cs_val in fp32 after bias / activation and before
+ * the rounding to 16 bits (cs_lo, cs_hi multiples of 128).  The fused q/k/v projection uses it to hand mio_fa3_fwd a K that
+ * already carries softmax_scale * log2(e) with a single rounding (k_prescaled).  Only where mio_gemm_col_scale_ok() != 0
+ * (the persistent 256x256-tile kernel takes the launch). */
+int32_t mio_gemm_col_scale_ok(int64_t M, int32_t N, int32_t K, int32_t act);
+int mio_gemm_bias_act_bw_cs(const void* x, const void* wb, const void* bias, void* y, int64_t M, int32_t N, int32_t K,
+                            int64_t ldx, int64_t ldy, int32_t act, int32_t dtype, int32_t x_blocked, int32_t cs_lo,
+                            int32_t cs_hi, float cs_val, void* stream);
 int32_t mio_fused_mlp_blocked_weight_ok(int64_t M, int32_t d, int32_t I, int32_t act);
 int mio_fused_mlp_fwd_bw(const void* x, const void* w1b, const void* b1, const void* w2b, const void* b2,
                          const void* residual, void* y, void* workspace, int64_t M, int32_t d, int32_t I, int32_t act,

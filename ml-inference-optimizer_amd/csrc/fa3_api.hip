@@ -12,6 +12,13 @@ extern template int fa3_launch<_Float16, 128>(const FaDev&, int, int, hipStream_
 
 static bool strides_ok(const int64_t s[3]) { return (s[0] % 8 == 0) && (s[1] % 8 == 0) && (s[2] % 8 == 0); }
 
+extern "C" int32_t mio_fa3_k_prescaled_ok(const mio_fa3_fwd_params_t* a) {
+  if (a == nullptr) return 0;
+  const bool span32 = (int64_t)a->Sk * a->k_stride[1] * 2 < (1ll << 32) && (int64_t)a->Sk * a->v_stride[1] * 2 < (1ll << 32);
+  return (a->D <= 64 && a->mask_kind == MIO_MASK_NONE && a->Sq > 128 && span32 && a->o != nullptr && a->o_acc == nullptr &&
+          !a->carry_in) ? 1 : 0;
+}
+
 extern "C" int mio_fa3_fwd(const mio_fa3_fwd_params_t* a, void* stream) {
   MIO_CHECK(a != nullptr, "mio_fa3_fwd: null params");
   MIO_CHECK(a->q && a->k && a->v, "mio_fa3_fwd: q/k/v must be non-null");
@@ -46,6 +53,9 @@ extern "C" int mio_fa3_fwd(const mio_fa3_fwd_params_t* a, void* stream) {
   p.qgrid = p.nqblk;
   p.xcd_remap = ((a->B * a->H) % 8 == 0) ? 1 : 0;
   p.scale_log2e = a->softmax_scale * FA_LOG2E;
+  p.k_prescaled = a->k_prescaled ? 1 : 0;
+  MIO_CHECK(!p.k_prescaled || mio_fa3_k_prescaled_ok(a), "mio_fa3_fwd: k_prescaled is not supported for this launch "
+                                                         "(mio_fa3_k_prescaled_ok == 0)");
 
   hipStream_t st = (hipStream_t)stream;
   const int dpad = a->D <= 64 ? 64 : (a->D <= 96 ? 96 : 128);

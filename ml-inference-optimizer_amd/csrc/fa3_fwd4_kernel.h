@@ -29,7 +29,21 @@ constexpr int FA4_SMEM = FA4_STAGES * FA4_STAGE;
 // the un-rounded exp values, per lane over its half of the keys) instead of the ones-MFMA.
 // (A staggered form -- waves 4-7 half a tile behind waves 0-3, PV of tile t-1 before QK^T / exp of tile t, 8 LDS stages --
 // was built and measured 4.5 % SLOWER than lockstep, 0.340 vs 0.325 ms)
-template <typename T, bool CAUSAL, int ABL = 0>
+//
+// KPRE (FaDev::k_prescaled): K arrives already multiplied by softmax_scale * log2(e) -- applied in fp32 in the epilogue of
+// the GEMM that produced it, before its one rounding to 16 bits (ops.gemm_bias_act col_scale=; scaling a 16-bit K or Q
+// afterwards would add a rounding and costs 3-5e-3 of lse accuracy).  Then the running reference enters the QK^T product
+// as the MFMA's C operand (a 16-register tuple holding -reference: one query per lane), S = K~ . Q^T - reference is
+// already the exp2 argument, and the 32 v_fma + 16 v_max3 per lane and tile of the scale / max pass are gone.  The rescale
+// trigger moves behind the exp: the reference is kept FA4_MARGIN above the running maximum, so P <= 2^-MARGIN normally, and
+// "some P >= 2" (the row outgrew the maximum by 2^(MARGIN + 1)) is bit 14 of a packed 16-bit word -- one v_or3_b32 per four
+// values; the rare branch recomputes the tile's P from the still intact scores.
+template <typename T>
+struct Fa4Margin { static constexpr float value = 5.0f; };   // bf16: exponent range of fp32
+template <>
+struct Fa4Margin<_Float16> { static constexpr float value = 2.0f; };  // fp16: keep the small probabilities out of the subnormals
+
+template <typename T, bool CAUSAL, int ABL = 0, bool KPRE = false>
 __global__ __launch_bounds__(512) void fa3_fwd4_kernel(const FaDev p) {
   using X8 = typename DT<T>::x8;
   using X4 = typename DT<T>::x4;
@@ -168,6 +182,15 @@ __global__ __launch_bounds__(512) void fa3_fwd4_kernel(const FaDev p) {
     // 0); negref = -reference as used by the scale-and-subtract
     float m_i = -INFINITY, negref = 0.f, mx = -INFINITY;
     float lsum = 0.f;  // (ABL & 64) this lane's partial row sum: its 32 of the tile's 64 keys
+    // KPRE state: ref = the reference subtracted through the MFMA's C operand (running maximum at the last move + margin;
+    // 0 while the row has seen no finite score), nref16 = -ref in every register, orw = OR of the tile's packed P words
+    float ref = 0.f;
+    bool fresh = true;
+    bool fresh_any = true;  // wave-uniform: some row of the wave is still fresh
+    uint32_t orw = 0u;
+    f32x16_t nref16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) nref16[i] = 0.f;
 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW) : "memory");  // tiles 0 and 1 have landed, tile 2 may still fly
     __syncthreads();
@@ -197,7 +220,7 @@ __global__ __launch_bounds__(512) void fa3_fwd4_kernel(const FaDev p) {
             f32x16_t z;
 #pragma unroll
             for (int i = 0; i < 16; ++i) z[i] = 0.f;
-            S[nb][tt] = DT<T>::mfma32(kf[ks][tt], qf[ks], z);
+            S[nb][tt] = DT<T>::mfma32(kf[ks][tt], qf[ks], KPRE ? nref16 : z);
           } else {
             S[nb][tt] = DT<T>::mfma32(kf[ks][tt], qf[ks], S[nb][tt]);
           }
@@ -237,6 +260,7 @@ __global__ __launch_bounds__(512) void fa3_fwd4_kernel(const FaDev p) {
         lsum += (e0 + e1) + (e2 + e3);
         asm volatile("" : "+v"(lsum));
       }
+      if constexpr (KPRE) orw |= w0 | w1;
       asm volatile("" ::"v"(w0), "v"(w1));  // a use in THIS step: keeps the work from sinking to its consumer in phase 2
       pfw[s][2 * half + 0] = w0;
       pfw[s][2 * half + 1] = w1;
@@ -265,11 +289,13 @@ __global__ __launch_bounds__(512) void fa3_fwd4_kernel(const FaDev p) {
           f32x16_t z;
 #pragma unroll
           for (int i = 0; i < 16; ++i) z[i] = 0.f;
-          S[nb][tt] = DT<T>::mfma32(kf[ks][tt], qf[ks], z);
+          S[nb][tt] = DT<T>::mfma32(kf[ks][tt], qf[ks], KPRE ? nref16 : z);
         } else {
           S[nb][tt] = DT<T>::mfma32(kf[ks][tt], qf[ks], S[nb][tt]);
         }
-        if constexpr (j < 5) half_unit(CB_, IC(j + 1));  // half-units 6 / 7 (k-step 3) ride in phase 2's fragment-read steps
+        // half-units 6 / 7 (k-step 3) ride in phase 2's fragment-read steps; KPRE: all eight here -- the rescale test
+        // needs the whole tile's P before any of it enters O
+        if constexpr (KPRE ? (j < 7) : (j < 5)) half_unit(CB_, IC(j + 1));
         if constexpr (j == 5) read_v(vb, IC(0));  // the first V fragments of phase 2, early: their LDS latency runs under steps 6 / 7
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -294,12 +320,12 @@ __global__ __launch_bounds__(512) void fa3_fwd4_kernel(const FaDev p) {
         }
         constexpr bool rd = (m == 0 && s < 3);
         if constexpr (rd) read_v(vb, IC(s + 1));
-        if constexpr (j == 0) half_unit(CB_, IC(6));
-        if constexpr (j == 3) half_unit(CB_, IC(7));
+        if constexpr (!KPRE && j == 0) half_unit(CB_, IC(6));
+        if constexpr (!KPRE && j == 3) half_unit(CB_, IC(7));
         // scale / max groups ride in the steps without a fragment read: group index = rank of this step among them
         constexpr int g = j - (s < 3 ? s + 1 : 3);  // steps before j that read: min(s + 1, 3) when m > 0 ... (m == 0: s)
         constexpr int grp = rd ? -1 : (m == 0 ? j - 3 : g);
-        if constexpr (DO_SCALE && !(ABL & 8) && grp >= 0 && grp < 8) {
+        if constexpr (!KPRE && DO_SCALE && !(ABL & 8) && grp >= 0 && grp < 8) {
           constexpr int tt = grp >> 2, r0 = 4 * (grp & 3);
           const float v0 = __builtin_fmaf(S[nb][tt][r0 + 0], c2, negref);
           const float v1 = __builtin_fmaf(S[nb][tt][r0 + 1], c2, negref);
@@ -373,6 +399,45 @@ __global__ __launch_bounds__(512) void fa3_fwd4_kernel(const FaDev p) {
         negref = -ref_new;
       }
     };
+    // KPRE: move the reference of rows that need it (fresh rows that now see a finite score; rows with some P >= 2), for
+    // the tile whose scores sit in S[cb] at the OLD reference.  REDO: also recompute that tile's P and shift S[cb ^ 1] (the
+    // next tile's scores, produced with the old C operand).  Rare: not scheduled.
+    auto move_ref = [&](auto CB_, auto REDO_) {
+      constexpr int cb = decltype(CB_)::value;
+      constexpr bool REDO = decltype(REDO_)::value != 0;
+      float mxl = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mxl = fmaxf(mxl, fmaxf(S[cb][0][i], S[cb][1][i]));
+      const float mxr = fmaxf(mxl, other_half(mxl));
+      const bool need = fresh ? (mxr != -INFINITY) : (mxr >= 1.0f);
+      const float delta = need ? mxr + Fa4Margin<T>::value : 0.f;
+      const float alpha = (need && !fresh) ? fast_exp2(-delta) : 1.f;  // a fresh row's O and L are still zero
+      if (need) fresh = false;
+      ref += delta;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        S[cb][0][i] -= delta;
+        S[cb][1][i] -= delta;
+        if constexpr (REDO) {
+          S[cb ^ 1][0][i] -= delta;
+          S[cb ^ 1][1][i] -= delta;
+        }
+        nref16[i] = -ref;
+      }
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          O[0][i] *= alpha;
+          O[1][i] *= alpha;
+          L[i] *= alpha;
+        }
+      }
+      if constexpr (REDO) {
+        orw = 0u;
+        fa2_for<8>([&](auto HU_) { half_unit(CB_, HU_); });
+      }
+      fresh_any = __builtin_amdgcn_ballot_w64(fresh) != 0;
+    };
     auto is_edge = [&](int t) -> bool { return t >= first_edge; };
     auto land = [&]() {  // this wave's share of tile t + 2 has landed (tile t + 3 may still fly); then everyone's
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW) : "memory");
@@ -385,18 +450,27 @@ __global__ __launch_bounds__(512) void fa3_fwd4_kernel(const FaDev p) {
     if (n_w > 0) {
       qk(IC(0), stg(0));
       if (is_edge(0)) mask_tile(IC(0), 0);
-      scale_max(IC(0));
-      update(IC(0));
+      if constexpr (KPRE) {
+        move_ref(IC(0), IC(0));
+      } else {
+        scale_max(IC(0));
+        update(IC(0));
+      }
     }
     // ---- tile loop (two tiles per trip: the score buffers alternate)
     auto iter = [&](int t, auto CB_) {
       constexpr int cb = decltype(CB_)::value;
       const bool has_next = (t + 1 < n_w);
+      if constexpr (KPRE) orw = 0u;
       phase1(CB_, stg(t + 1), stg(t));   // (after the last tile of the wave the QK^T half produces scores nobody reads)
+      if constexpr (KPRE) {
+        // some P >= 2 (bit 14 of a packed 16-bit word; inf and NaN included), or a row still waiting for its first score
+        if (__builtin_amdgcn_ballot_w64((orw & 0x40004000u) != 0u) != 0 || fresh_any) move_ref(CB_, IC(1));
+      }
       if (has_next && is_edge(t + 1)) mask_tile(IC(cb ^ 1), (t + 1) * FA_BN);
       if constexpr (!(ABL & 32)) stage_dma(t + 3);
       phase2(IC(cb ^ 1), stg(t), IC(1));
-      if constexpr (!(ABL & 8))
+      if constexpr (!KPRE && !(ABL & 8))
         if (has_next) update(IC(cb ^ 1));
       land();
     };
@@ -419,7 +493,7 @@ __global__ __launch_bounds__(512) void fa3_fwd4_kernel(const FaDev p) {
       const float l_tot = (ABL & 64) ? lsum + other_half(lsum) : L[0];
       const float inv = (l_tot > 0.f) ? fast_rcp(l_tot) : 0.f;
       if (q_ok && p.lse != nullptr && h == 0) {
-        const float lse = (l_tot > 0.f) ? (m_i + fast_log2(l_tot)) * FA_LN2 : -INFINITY;
+        const float lse = (l_tot > 0.f) ? ((KPRE ? ref : m_i) + fast_log2(l_tot)) * FA_LN2 : -INFINITY;
         p.lse[((int64_t)b * p.H + head) * p.Sq + qrow] = lse;
       }
       T* op = (T*)p.o + b * p.os_b + head * p.os_h + (int64_t)(q_ok ? qrow : 0) * p.os_s;

@@ -118,14 +118,14 @@ static int launch_three(FaDev p, hipStream_t stream) {
 
 // fourth structure (two waves per SIMD, 8 waves x 32 query rows): head dim <= 64, no user mask, plain output
 #if FA_D == 64
-template <bool CAUSAL>
+template <bool CAUSAL, bool KPRE = false>
 static int launch_four(FaDev p, hipStream_t stream) {
   p.nqblk = (p.Sq + FA4_BM - 1) / FA4_BM;
   p.qgrid = CAUSAL ? (p.nqblk + 1) / 2 : p.nqblk;
   const int grid = p.qgrid * p.B * p.H;
-  void (*kern)(const FaDev) = fa3_fwd4_kernel<FaT, CAUSAL>;
+  void (*kern)(const FaDev) = fa3_fwd4_kernel<FaT, CAUSAL, 0, KPRE>;
 #if defined(MIO_DIAG) && FA_TYPE_ID == 0
-  if constexpr (CAUSAL) {  // timing-only ablations (tools/fa4_ablate.py)
+  if constexpr (CAUSAL && !KPRE) {  // timing-only ablations (tools/fa4_ablate.py)
     void (*ka)(const FaDev) = nullptr;
     switch (mio_dbg_get(0)) {
       case 1: ka = fa3_fwd4_kernel<FaT, CAUSAL, 1>; break;
@@ -186,6 +186,10 @@ int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t
   // keep fa3_fwd3, = 4 force fa3_fwd4 for non-causal launches too.
   {
     const bool plain = mask_kind == MIO_MASK_NONE && p.Sq > 128 && span32 && p.o != nullptr && p.o_acc == nullptr && !p.carry_in;
+    if (p.k_prescaled) {  // (mio_fa3_fwd has checked mio_fa3_k_prescaled_ok: plain holds)
+      if (!plain) return mio_fail("fa3_fwd: k_prescaled launch outside the fa3_fwd4 path");
+      return causal ? launch_four<true, true>(p, stream) : launch_four<false, true>(p, stream);
+    }
     bool four = plain && causal && fa_impl() == 0;
 #ifdef MIO_DIAG
     if (mio_dbg_get(1) == 3) four = false;

@@ -41,6 +41,7 @@ struct FaDev {
   int nqblk, xcd_remap;
   int qgrid;  // workgroups per (batch, head): nqblk, or ceil(nqblk/2) when causal blocks are paired (fa3_fwd2)
   float scale_log2e;  // softmax_scale * log2(e)
+  int k_prescaled;    // K already carries softmax_scale * log2(e) (fa3_fwd4_kernel KPRE; mio_fa3_k_prescaled_ok)
 };
 
 constexpr int FA_BM = 128;

@@ -300,6 +300,10 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) bq[nt] = *(const u32x2_t*)(bl + nt * 32);
       }
+      // column scale: wave-uniform (the wave's 128 columns lie inside or outside [cs_lo, cs_hi))
+      const int ncol0 = on0 + wc * 128;
+      const float csv = (ncol0 >= p.cs_lo && ncol0 < p.cs_hi) ? p.cs_val : 1.0f;
+      const f32x2_t cs2 = {csv, csv};
       auto pair = [&](auto MTP) {
         constexpr int mtp = decltype(MTP)::value, mt = 2 * mtp;
         auto col = [&](auto NT) {
@@ -308,8 +312,8 @@ __global__ __launch_bounds__(256) void gemm4w16p_kernel(const GemmDev p) {
           const f32x4_t a = G6AccIO<nt * 8 + mt>::read();
           const f32x4_t b = G6AccIO<nt * 8 + mt + 1>::read();
           const f32x2_t b01 = {(float)bv[0], (float)bv[1]}, b23 = {(float)bv[2], (float)bv[3]};
-          const f32x2_t a01 = gemm_act2<ACT>((f32x2_t){a[0], a[1]} + b01), a23 = gemm_act2<ACT>((f32x2_t){a[2], a[3]} + b23);
-          const f32x2_t c01 = gemm_act2<ACT>((f32x2_t){b[0], b[1]} + b01), c23 = gemm_act2<ACT>((f32x2_t){b[2], b[3]} + b23);
+          const f32x2_t a01 = gemm_act2<ACT>((f32x2_t){a[0], a[1]} + b01) * cs2, a23 = gemm_act2<ACT>((f32x2_t){a[2], a[3]} + b23) * cs2;
+          const f32x2_t c01 = gemm_act2<ACT>((f32x2_t){b[0], b[1]} + b01) * cs2, c23 = gemm_act2<ACT>((f32x2_t){b[2], b[3]} + b23) * cs2;
           const auto s0 = __builtin_amdgcn_permlane16_swap(pack2<T>(a01[0], a01[1]), pack2<T>(c01[0], c01[1]), false, false);
           const auto s1 = __builtin_amdgcn_permlane16_swap(pack2<T>(a23[0], a23[1]), pack2<T>(c23[0], c23[1]), false, false);
           ob0[mtp * 8 + nt] = s0[0];

@@ -55,6 +55,7 @@ extern "C" int mio_gemm_bias_act(const void* x, const void* w, const void* bias,
   p.x_blk = p.y_blk = 0;
   p.w_blk = 0;
   p.dbg = nullptr;
+  p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f;
   return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
 }
 
@@ -92,6 +93,8 @@ static int fused_mlp_impl(const void* x, const void* w1, const void* b1, const v
     p.tiles_m = p.tiles_n = 0;
     p.x_blk = xblk; p.y_blk = 1; p.w_blk = wblk;
     p.dbg = nullptr;
+    p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f;
+  p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f;
     int rc = gemm_dispatch(p, act, dtype, (hipStream_t)stream);
     if (rc != 0) return rc;
     p.x = workspace; p.w = w2; p.bias = b2; p.res = residual; p.y = y;
@@ -180,6 +183,39 @@ extern "C" int mio_gemm_bias_act_bw(const void* x, const void* wb, const void* b
   p.tiles_m = p.tiles_n = 0;
   p.x_blk = x_blocked ? 1 : 0; p.y_blk = 0; p.w_blk = 1;
   p.dbg = nullptr;
+  p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f;
+  return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
+}
+
+// column scale: the launch must end in the persistent kernel (gemm_inst.hip launch_act): blocked weight shape, no residual,
+// K >= 256, K % 64 == 0
+extern "C" int32_t mio_gemm_col_scale_ok(int64_t M, int32_t N, int32_t K, int32_t act) {
+  return (gemm_blocked_w_ok(M, N, K, act) && mio_gemm_impl() == 0 && K >= 256 && K % 64 == 0 && N % 8 == 0) ? 1 : 0;
+}
+
+extern "C" int mio_gemm_bias_act_bw_cs(const void* x, const void* wb, const void* bias, void* y, int64_t M, int32_t N,
+                                       int32_t K, int64_t ldx, int64_t ldy, int32_t act, int32_t dtype, int32_t x_blocked,
+                                       int32_t cs_lo, int32_t cs_hi, float cs_val, void* stream) {
+  MIO_CHECK(x && wb && y, "mio_gemm_bias_act_bw_cs: x, wb, y must be non-null");
+  MIO_CHECK(M >= 0 && N > 0 && K > 0, "mio_gemm_bias_act_bw_cs: bad sizes");
+  MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_gemm_bias_act_bw_cs: dtype must be bf16 or fp16");
+  MIO_CHECK(act >= MIO_ACT_NONE && act < MIO_ACT_SWIGLU, "mio_gemm_bias_act_bw_cs: unknown / unsupported activation");
+  if (x_blocked) ldx = K;
+  MIO_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= K && ldy >= N, "mio_gemm_bias_act_bw_cs: bad strides");
+  MIO_CHECK(mio_aligned16(x) && mio_aligned16(wb) && mio_aligned16(y) && mio_aligned16(bias),
+            "mio_gemm_bias_act_bw_cs: pointers must be 16-byte aligned");
+  MIO_CHECK(ldx * 512 < (int64_t)0x7fffffff && ldy * 512 < (int64_t)0x7fffffff, "mio_gemm_bias_act_bw_cs: row stride too large");
+  MIO_CHECK(mio_gemm_col_scale_ok(M, N, K, act), "mio_gemm_bias_act_bw_cs: this shape does not run the persistent kernel "
+                                                 "(mio_gemm_col_scale_ok == 0)");
+  MIO_CHECK(cs_lo >= 0 && cs_hi <= N && cs_lo % 128 == 0 && cs_hi % 128 == 0 && cs_lo <= cs_hi,
+            "mio_gemm_bias_act_bw_cs: [cs_lo, cs_hi) must be multiples of 128 inside [0, N]");
+  GemmDev p;
+  p.x = x; p.w = wb; p.wg = nullptr; p.bias = bias; p.bias_g = nullptr; p.res = nullptr; p.y = y;
+  p.M = M; p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.ldr = 0; p.N = N; p.K = K;
+  p.tiles_m = p.tiles_n = 0;
+  p.x_blk = x_blocked ? 1 : 0; p.y_blk = 0; p.w_blk = 1;
+  p.dbg = nullptr;
+  p.cs_lo = cs_lo; p.cs_hi = cs_hi; p.cs_val = cs_val;
   return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
 }
 

@@ -37,6 +37,12 @@ struct GemmDev {
   // Blocked weight (mio_weight_block, one-time repack): the same layout with n in the place of m, rows padded to 256.
   int w_blk;
   unsigned long long* dbg;  // diagnostic builds only (in-kernel stamps); nullptr otherwise
+  // Column scale (persistent kernel only): output columns [cs_lo, cs_hi) are multiplied by cs_val in fp32 AFTER bias /
+  // activation and BEFORE the rounding to 16 bits; cs_lo, cs_hi multiples of 128 (a wave's column range is inside or
+  // outside).  Use: the fused QKV projection hands the attention kernel K * softmax_scale * log2(e) with ONE rounding
+  // (mio_fa3_fwd k_prescaled).  cs_lo >= cs_hi: off.
+  int cs_lo, cs_hi;
+  float cs_val;
 };
 
 int mio_gemm_impl();  // MIO_GEMM_IMPL override (0 = default dispatch); defined in gemm_api.hip

@@ -28,6 +28,7 @@ EXPORTS = (
     "mio_version",
     "mio_last_error",
     "mio_fa3_fwd",
+    "mio_fa3_k_prescaled_ok",
     "mio_attn_merge",
     "mio_gemm_bias_act",
     "mio_fused_mlp_workspace_bytes",
@@ -36,6 +37,8 @@ EXPORTS = (
     "mio_weight_block",
     "mio_gemm_blocked_weight_ok",
     "mio_gemm_bias_act_bw",
+    "mio_gemm_col_scale_ok",
+    "mio_gemm_bias_act_bw_cs",
     "mio_fused_mlp_blocked_weight_ok",
     "mio_fused_mlp_fwd_bw",
     "mio_layernorm_fwd_bx",
@@ -75,6 +78,7 @@ class FaParams(C.Structure):
         ("q_offset", C.c_int32),
         ("k_offset", C.c_int32),
         ("softmax_scale", C.c_float),
+        ("k_prescaled", C.c_int32),
     ]
 
 
@@ -93,6 +97,8 @@ def _load() -> C.CDLL:
     lib.mio_last_error.restype = C.c_char_p
     lib.mio_fa3_fwd.argtypes = [C.POINTER(FaParams), vp]
     lib.mio_fa3_fwd.restype = i32
+    lib.mio_fa3_k_prescaled_ok.argtypes = [C.POINTER(FaParams)]
+    lib.mio_fa3_k_prescaled_ok.restype = i32
     lib.mio_attn_merge.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.mio_attn_merge.restype = i32
     lib.mio_gemm_bias_act.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i64, i32, i32, vp]
@@ -109,6 +115,10 @@ def _load() -> C.CDLL:
     lib.mio_gemm_blocked_weight_ok.restype = i32
     lib.mio_gemm_bias_act_bw.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i32, i32, i32, vp]
     lib.mio_gemm_bias_act_bw.restype = i32
+    lib.mio_gemm_col_scale_ok.argtypes = [i64, i32, i32, i32]
+    lib.mio_gemm_col_scale_ok.restype = i32
+    lib.mio_gemm_bias_act_bw_cs.argtypes = [vp, vp, vp, vp, i64, i32, i32, i64, i64, i32, i32, i32, i32, i32, f32, vp]
+    lib.mio_gemm_bias_act_bw_cs.restype = i32
     lib.mio_fused_mlp_blocked_weight_ok.argtypes = [i64, i32, i32, i32]
     lib.mio_fused_mlp_blocked_weight_ok.restype = i32
     lib.mio_fused_mlp_fwd_bw.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]

@@ -63,18 +63,19 @@ class CastCache:
 
 
 def linear(x: torch.Tensor, lin: nn.Linear, cache: CastCache, dtype: torch.dtype, activation: str = "none",
-           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, col_scale=None) -> torch.Tensor:
     """F.linear(x, W, b) (+ activation, + residual) on the MFMA GEMM.  At sizes that run the 256x256-tile kernels the
     weight is handed over in the blocked layout (repacked once per parameter version, cached next to the cast copy)."""
     w = cache.get(lin.weight, dtype)
     N, K = w.shape
     M = x.numel() // K
     wb = cache.get_blocked(lin.weight, dtype) if (K % 32 == 0 and ops.blocked_weight_ok(M, N, K, activation)) else None
-    return ops.gemm_bias_act(x, w, cache.get(lin.bias, dtype), activation, residual=residual, w_blocked=wb)
+    return ops.gemm_bias_act(x, w, cache.get(lin.bias, dtype), activation, residual=residual, w_blocked=wb,
+                             col_scale=col_scale)
 
 
 def prenorm_linear(x: torch.Tensor, ln: nn.LayerNorm, lin: nn.Linear, cache: CastCache, dtype: torch.dtype,
-                   activation: str = "none", residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   activation: str = "none", residual: Optional[torch.Tensor] = None, col_scale=None) -> torch.Tensor:
     """lin(ln(x)) (+ activation, + residual).  At sizes that run the 256x256-tile kernels LayerNorm writes its output in
     the blocked activation layout, so the GEMM's K-tile fetches are contiguous on both operands."""
     w = cache.get(lin.weight, dtype)
@@ -84,5 +85,6 @@ def prenorm_linear(x: torch.Tensor, ln: nn.LayerNorm, lin: nn.Linear, cache: Cas
     if K % 32 == 0 and not ops.NO_BLOCKED_X and ops.blocked_weight_ok(M, N, K, activation):
         xb = ops.layernorm(x, lw, lb, ln.eps, out_blocked=True)
         return ops.gemm_bias_act(xb, w, cache.get(lin.bias, dtype), activation, residual=residual,
-                                 w_blocked=cache.get_blocked(lin.weight, dtype), x_blocked_shape=tuple(x.shape))
-    return linear(ops.layernorm(x, lw, lb, ln.eps), lin, cache, dtype, activation, residual)
+                                 w_blocked=cache.get_blocked(lin.weight, dtype), x_blocked_shape=tuple(x.shape),
+                                 col_scale=col_scale)
+    return linear(ops.layernorm(x, lw, lb, ln.eps), lin, cache, dtype, activation, residual, col_scale=col_scale)

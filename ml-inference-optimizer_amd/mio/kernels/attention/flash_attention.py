@@ -212,12 +212,31 @@ class FlashSelfAttention(_AttentionBase):
             q2d = ops.gemm_bias_act(x, wq, None if bq is None else bq[:q_dim].contiguous())
             out = self._paged(q2d, B, S, dt, kwargs, "FlashSelfAttention", r)
             return out if in_dtype == dt else out.to(in_dtype)
-        # [B,S,q_dim+2*kv_dim]; q/k/v are strided views of it
-        qkv = linear(x, self.qkv_proj, c, dt) if pre_norm is None else prenorm_linear(x, pre_norm, self.qkv_proj, c, dt)
+        # [B,S,q_dim+2*kv_dim]; q/k/v are strided views of it.  Where the kernels allow it the projection's epilogue hands
+        # over K * softmax_scale * log2(e) (scaled in fp32, rounded once): the attention kernel then takes the running
+        # reference through the MFMA's C operand and drops its per-score multiply-subtract / max pass (ops.fa3_fwd k_prescaled)
+        n_tot = q_dim + 2 * kv_dim
+        cfg = self.config
+        kpre = (attention_mask is None and not cfg.normalize_query and not cfg.return_softmax and q_dim % 128 == 0
+                and kv_dim % 128 == 0 and self.qkv_proj.in_features % 32 == 0
+                and ops.fa3_k_prescaled_ok(B, S, S, self.num_attention_heads, self.head_dim, n_tot, n_tot)
+                and ops.blocked_weight_ok(B * S, n_tot, self.qkv_proj.in_features)
+                and ops.col_scale_ok(B * S, n_tot, self.qkv_proj.in_features))
+        cs = None
+        if kpre:
+            sc = cfg.softmax_scale if cfg.softmax_scale is not None else 1.0 / math.sqrt(self.head_dim)
+            cs = (q_dim, q_dim + kv_dim, sc * 1.4426950408889634)
+        qkv = (linear(x, self.qkv_proj, c, dt, col_scale=cs) if pre_norm is None
+               else prenorm_linear(x, pre_norm, self.qkv_proj, c, dt, col_scale=cs))
         q = qkv[:, :, :q_dim].view(B, S, self.num_attention_heads, self.head_dim)
         k = qkv[:, :, q_dim:q_dim + kv_dim].view(B, S, self.num_kv_heads, self.head_dim)
         v = qkv[:, :, q_dim + kv_dim:].view(B, S, self.num_kv_heads, self.head_dim)
-        ctx = self._attend(q, k, v, attention_mask).view(B, S, self.hidden_size)
+        if kpre:
+            if self.training and cfg.dropout_p > 0.0:
+                raise NotImplementedError("attention dropout (training) is not supported by the inference kernel")
+            ctx = ops.fa3_fwd(q, k, v, causal=cfg.causal, k_prescaled=True).view(B, S, self.hidden_size)
+        else:
+            ctx = self._attend(q, k, v, attention_mask).view(B, S, self.hidden_size)
         out = linear(ctx, self.o_proj, c, dt, residual=r)
         return out if in_dtype == dt else out.to(in_dtype)
 

@@ -110,12 +110,15 @@ def fa3_fwd(
     write_out: bool = True,
     q_offset: int = 0,
     k_offset: int = 0,
+    k_prescaled: bool = False,
 ):
     """One launch of the tiled attention kernel.
 
     layout "bshd": q [B,Sq,H,D], k/v [B,Sk,Hkv,D] (flash); "bhsd": head-major (ring, a9).
     keep_mask / additive_mask: 4-D, broadcastable to [B,H,Sq,Sk] (size-1 dims broadcast).
     Ring carry: o_acc fp32 [B,Sq,H,D] + lse fp32 [B,H,Sq]; carry_in continues from that state.
+    k_prescaled: k already holds K * softmax_scale * log2(e), scaled in fp32 before its rounding to 16 bits
+    (gemm_bias_act(col_scale=...)); only where fa3_k_prescaled_ok() says so -- ValueError otherwise.
     Returns out (same layout as q) or (out, lse) if return_lse.
     """
     _need_cuda(q, k, v)
@@ -194,10 +197,19 @@ def fa3_fwd(
     p.B, p.Sq, p.Sk, p.H, p.Hkv, p.D = B, Sq, Sk, H, Hkv, D
     p.dtype, p.causal, p.mask_kind, p.carry_in = dt, int(bool(causal)), kind, int(bool(carry_in))
     p.q_offset, p.k_offset, p.softmax_scale = int(q_offset), int(k_offset), scale
+    if k_prescaled:
+        if not lib.mio_fa3_k_prescaled_ok(C.byref(p)):
+            raise ValueError("k_prescaled is only supported for head_dim <= 64, no mask, no (o_acc, lse) carry, Sq > 128")
+        p.k_prescaled = 1
     check(lib.mio_fa3_fwd(C.byref(p), _stream()))
     if return_lse:
         return out, lse
     return out
+
+
+def fa3_k_prescaled_ok(B: int, Sq: int, Sk: int, H: int, D: int, k_row_stride: int, v_row_stride: int) -> bool:
+    """True iff fa3_fwd(..., k_prescaled=True) is available for a plain (no mask, no carry) launch of this geometry."""
+    return D <= 64 and Sq > 128 and Sk * k_row_stride * 2 < (1 << 32) and Sk * v_row_stride * 2 < (1 << 32)
 
 
 def _canon_mask4(mask: torch.Tensor) -> torch.Tensor:
@@ -302,9 +314,16 @@ def fused_mlp_blocked_weight_ok(M: int, d: int, I: int, activation: str) -> bool
     return not _NO_BLOCKED_W and bool(lib.mio_fused_mlp_blocked_weight_ok(M, d, I, _ACT.get(activation, _lib.ACT_NONE)))
 
 
+def col_scale_ok(M: int, N: int, K: int, activation: str = "none") -> bool:
+    """True iff gemm_bias_act(..., col_scale=) is available for this shape (the persistent 256x256-tile kernel runs it)."""
+    return not _NO_BLOCKED_W and bool(lib.mio_gemm_col_scale_ok(M, N, K, _ACT.get(activation, _lib.ACT_NONE)))
+
+
 def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_gate=None, residual=None, out=None,
-                  w_blocked=None, x_blocked_shape=None):
-    """y = act(x @ w^T + bias) (+ residual); x [..., K], w [N, K].  F.linear with a fused epilogue."""
+                  w_blocked=None, x_blocked_shape=None, col_scale=None):
+    """y = act(x @ w^T + bias) (+ residual); x [..., K], w [N, K].  F.linear with a fused epilogue.
+    col_scale = (lo, hi, value): output columns [lo, hi) are multiplied by value in fp32 before the rounding to the
+    storage dtype (lo, hi multiples of 128; needs w_blocked, no residual, and col_scale_ok())."""
     _need_cuda(x, w)
     if activation not in _ACT:
         raise ValueError(f"Unsupported activation function: {activation}")
@@ -319,6 +338,26 @@ def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_g
     _vec_ok(bias, N, x.dtype, "bias")
     if act == _lib.ACT_SWIGLU:
         _vec_ok(bias_gate, N, x.dtype, "bias_gate")
+    if col_scale is not None:
+        lo, hi, val = int(col_scale[0]), int(col_scale[1]), float(col_scale[2])
+        Mcs = int(math.prod(x_blocked_shape[:-1])) if x_blocked_shape is not None else x.numel() // K
+        if w_blocked is None or residual is not None or not lib.mio_gemm_col_scale_ok(Mcs, N, K, act):
+            raise ValueError("col_scale needs a blocked weight, no residual and a shape with col_scale_ok()")
+        if lo % 128 or hi % 128 or not (0 <= lo <= hi <= N):
+            raise ValueError(f"col_scale range [{lo}, {hi}) must be multiples of 128 inside [0, {N}]")
+        if x_blocked_shape is not None:
+            xs, ldx, xb = x, K, 1
+            lead = tuple(x_blocked_shape[:-1])
+        else:
+            xs = _rows16(x.reshape(-1, K))
+            ldx, xb = xs.stride(0), 0
+            lead = tuple(x.shape[:-1])
+        if out is None:
+            out = torch.empty(*lead, N, dtype=x.dtype, device=x.device)
+        y2 = out.view(-1, N)
+        check(lib.mio_gemm_bias_act_bw_cs(xs.data_ptr(), w_blocked.data_ptr(), _ptr(bias), y2.data_ptr(), Mcs, N, K, ldx,
+                                          y2.stride(0), act, dt, xb, lo, hi, val, _stream()))
+        return out
     if x_blocked_shape is not None:
         # x is layernorm(..., out_blocked=True) of a tensor of shape x_blocked_shape: blocked activation layout
         M = int(math.prod(x_blocked_shape[:-1]))

@@ -124,6 +124,69 @@ def test_fa3_benchmark_length(dtype, causal, D, S, H):
     assert (lse - torch.logsumexp(s, -1)).abs().max().item() < (2e-3 if dtype == torch.float16 else 6e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Sq,Sk,H,Hkv,D,causal,q_off,k_off", [
+    (2, 300, 300, 4, 4, 64, True, 0, 0), (1, 257, 130, 6, 2, 64, False, 0, 0), (1, 511, 511, 6, 2, 64, True, 0, 0),
+    (1, 256, 192, 6, 2, 64, True, 64, 128),   # partial overlap: rows that see no key stay "fresh" for the whole pass
+    (1, 130, 300, 6, 2, 64, True, 170, 0), (1, 192, 192, 3, 3, 32, True, 0, 0), (1, 2048, 2048, 8, 8, 64, True, 0, 0),
+    (1, 2048, 2048, 4, 4, 64, False, 0, 0),
+])
+def test_fa3_k_prescaled(dtype, B, Sq, Sk, H, Hkv, D, causal, q_off, k_off):
+    """k_prescaled launches (fa3_fwd4_kernel KPRE: reference through the MFMA's C operand, post-exp rescale test on
+    bit 14 of the packed P words): K~ = round16(K * softmax_scale * log2 e) computed in fp32 -- what the projection's
+    col_scale epilogue hands over -- against the oracle evaluated on (q, K~, v) with scores q . K~ * ln 2.  q is scaled
+    up at the long sequence so that rows outgrow their reference by more than 2^(margin + 1) several times (the rare
+    branch that recomputes a tile's P)."""
+    import math
+    ops = _ops()
+    torch.manual_seed(Sq + 3 * Sk + D)
+    q = (torch.randn(B, Sq, H, D) * (3 if Sq >= 2048 else 1)).to(dtype)
+    kt = (torch.randn(B, Sk, Hkv, D) * (math.log2(math.e) / math.sqrt(D))).to(dtype)
+    v = torch.randn(B, Sk, Hkv, D).to(dtype)
+    o, lse = ops.fa3_fwd(q.to(DEV), kt.to(DEV), v.to(DEV), causal=causal, q_offset=q_off, k_offset=k_off, return_lse=True,
+                         k_prescaled=True)
+    ref, rlse = oracle.attention_with_lse(q, kt, v, causal=causal, q_offset=q_off, k_offset=k_off,
+                                          softmax_scale=math.log(2.0))
+    empty = torch.isinf(rlse)
+    assert torch.equal(torch.isinf(lse.cpu()), empty)
+    if (~empty).any():
+        assert (lse.cpu().double() - rlse)[~empty].abs().max() < (6e-3 if dtype == torch.bfloat16 else 2e-3)
+    keep = (~empty).permute(0, 2, 1)[..., None].expand_as(ref)
+    if keep.any():
+        _cmp(o.cpu()[keep], ref[keep], dtype, "o")
+    assert (o.cpu()[~keep] == 0).all()
+    with pytest.raises(ValueError):  # outside the kernel that supports it: refused, not silently ignored
+        ops.fa3_fwd(q[:, :64].to(DEV), kt.to(DEV), v.to(DEV), k_prescaled=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_col_scale(dtype):
+    """Column-scale epilogue of the persistent GEMM: columns [lo, hi) = round16(value * (x w^T + b)) -- scaled in fp32
+    before the one rounding -- and every other column bit-identical to the plain launch."""
+    ops = _ops()
+    torch.manual_seed(13)
+    M, N, K = 8192 + 40, 3072, 512
+    x = torch.randn(M, K).to(dtype)
+    w = (torch.randn(N, K) * 0.05).to(dtype)
+    b = torch.randn(N).to(dtype)
+    wb = ops.block_weight(w.to(DEV))
+    assert ops.col_scale_ok(M, N, K)
+    val, lo, hi = 0.18033688, 1024, 2048
+    y0 = ops.gemm_bias_act(x.to(DEV), w.to(DEV), b.to(DEV), w_blocked=wb)
+    y1 = ops.gemm_bias_act(x.to(DEV), w.to(DEV), b.to(DEV), w_blocked=wb, col_scale=(lo, hi, val))
+    assert torch.equal(y1[:, :lo], y0[:, :lo]) and torch.equal(y1[:, hi:], y0[:, hi:])
+    want = ((x.float() @ w.float().T).double() + b.double())[:, lo:hi] * val
+    _cmp(y1[:, lo:hi], want, dtype, "scaled columns")
+    # a single rounding: tighter than scaling the already rounded plain result
+    once = (y1[:, lo:hi].float().cpu().double() - want).abs().mean()
+    twice = ((y0[:, lo:hi].float() * val).to(dtype).float().cpu().double() - want).abs().mean()
+    assert once < twice
+    with pytest.raises(ValueError):
+        ops.gemm_bias_act(x.to(DEV), w.to(DEV), b.to(DEV), w_blocked=wb, col_scale=(100, 2048, val))
+    with pytest.raises(ValueError):
+        ops.gemm_bias_act(x[:64].to(DEV), w.to(DEV), b.to(DEV), w_blocked=wb, col_scale=(lo, hi, val))
+
+
 @pytest.mark.parametrize("case", ["d64_nomask", "d64_additive", "d64_causal", "d80_cross", "d128_causal", "d64_padding"])
 def test_ring_forward_vs_golden(golden_dir, case):
     """HIP kernel vs the outputs of the reference's own ring fallback (tests/golden)."""

@@ -55,24 +55,57 @@ for dtype in (torch.bfloat16, torch.float16):
         bad += 0 if good else 1
         print(f"{str(dtype)[6:]:9s} B{B} Sq{Sq} Sk{Sk} H{H}/{Hkv} D{D} causal={int(causal)} off=({qo},{ko}): fwd4 rel {r4:.2e} lse {dl:.1e} | fwd3 rel {r3:.2e} {'ok' if good else 'FAIL'}", flush=True)
 print("FAILURES:", bad, flush=True)
+# ---- k_prescaled launches: K~ = round16(K * softmax_scale * log2 e), reference = base-2 softmax of q . K~^T
+import math
+badk = 0
+for dtype in (torch.bfloat16, torch.float16):
+    for (B, Sq, Sk, H, Hkv, D, causal, qo, ko) in cases:
+        if Sq <= 128:
+            continue
+        torch.manual_seed(Sq + Sk + 1)
+        q = (torch.randn(B, Sq, H, D, device=dev) * (3 if Sq >= 4096 else 1)).to(dtype)
+        k32 = torch.randn(B, Sk, Hkv, D, device=dev)
+        v = torch.randn(B, Sk, Hkv, D, device=dev).to(dtype)
+        c2 = math.log2(math.e) / math.sqrt(D)
+        kt = (k32 * c2).to(dtype)
+        o4, l4 = ops.fa3_fwd(q, kt, v, causal=causal, q_offset=qo, k_offset=ko, return_lse=True, k_prescaled=True)
+        # reference: natural-exp softmax of (q . kt) * ln 2  ==  base-2 softmax of q . kt
+        ro, rl = ref_attn(q, (kt.float() * math.log(2.0) * math.sqrt(D)), v, causal, qo, ko)
+        empty = torch.isinf(rl)
+        keep = (~empty).permute(0, 2, 1)[..., None].expand_as(ro)
+        r4 = ((o4.float()[keep] - ro[keep]).abs().mean() / ro[keep].abs().mean()).item() if keep.any() else 0.0
+        dl = (l4 - rl)[~empty].abs().max().item() if (~empty).any() else 0.0
+        z = (o4.float()[~keep] == 0).all().item() if (~keep).any() else True
+        tol = 3e-3 if dtype == torch.bfloat16 else 1e-3
+        good = torch.equal(torch.isinf(l4), empty) and r4 < tol and dl < (6e-3 if dtype == torch.bfloat16 else 2e-3) and z
+        badk += 0 if good else 1
+        print(f"KPRE {str(dtype)[6:]:9s} B{B} Sq{Sq} Sk{Sk} H{H}/{Hkv} D{D} causal={int(causal)} off=({qo},{ko}): rel {r4:.2e} lse {dl:.1e} {'ok' if good else 'FAIL'}", flush=True)
+print("KPRE FAILURES:", badk, flush=True)
 # ---- timing
 B, S, H, D = 8, 4096, 16, 64
 torch.manual_seed(0)
 q, k, v = (torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16) for _ in range(3))
 o = torch.empty_like(q)
+kpre = (torch.randn(B, S, H, D, device=dev) * (math.log2(math.e) / math.sqrt(D))).to(torch.bfloat16)
+KP = False
 def run(n, causal):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(n):
-        ops.fa3_fwd(q, k, v, causal=causal, out=o)
+        if KP:
+            ops.fa3_fwd(q, kpre, v, causal=causal, out=o, k_prescaled=True)
+        else:
+            ops.fa3_fwd(q, k, v, causal=causal, out=o)
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 VAR = int(os.environ.get("FA4_VAR", "0"))  # fwd4 variant (mio_dbg_set(0, VAR)); e.g. 64 = row sums on the vector ALU
 def sel(impl):
+    global KP
+    KP = (impl == 6)
     _lib.lib.mio_dbg_set(1, 4 if impl >= 4 else 3)
     _lib.lib.mio_dbg_set(0, VAR if impl == 5 else 0)
 for causal in (True, False):
-    impls = (3, 4, 5) if (VAR and causal) else (3, 4)
+    impls = (3, 4, 5, 6) if (VAR and causal) else (3, 4, 6)
     res = {i: [] for i in impls}
     for impl in impls:
         sel(impl); run(200, causal)
@@ -82,7 +115,7 @@ for causal in (True, False):
     fl = (2.0 * B * S * (S + 1) * H * D) if causal else 4.0 * B * S * S * H * D
     for impl in impls:
         t = min(res[impl])
-        print(f"causal={int(causal)} fwd{impl if impl < 5 else '4/var' + str(VAR)}: min {t:.4f} ms  {fl / t / 1e9:.0f} TFLOP/s  frac {fl / t / 1e9 / 2500:.3f}", flush=True)
+        print(f"causal={int(causal)} fwd{impl if impl < 5 else ('4/var' + str(VAR) if impl == 5 else '4/k_prescaled')}: min {t:.4f} ms  {fl / t / 1e9:.0f} TFLOP/s  frac {fl / t / 1e9 / 2500:.3f}", flush=True)
 if VAR:  # the variant's values (causal bf16 only is instantiated)
     _lib.lib.mio_dbg_set(1, 4); _lib.lib.mio_dbg_set(0, VAR)
     o5, l5 = ops.fa3_fwd(q, k, v, causal=True, return_lse=True)
