@@ -31,12 +31,16 @@ def short(name):
             return f"{k}<{dt},{ACT.get(vals[-1], vals[-1])}>"
         if k in ("fa3_fwd_kernel", "fa3_fwd2_kernel"):
             return f"{k}<{dt},D{vals[0]},{'causal' if vals[1] == '1' else 'full'}>"
+        if k == "fa3_fwd4_kernel":  # <T, CAUSAL, ABL, KPRE>
+            return f"{k}<{dt},{'causal' if vals[0] == '1' else 'full'}{',k_prescaled' if vals[-1] == '1' and len(vals) >= 3 else ''}>"
         if k == "fa3_fwd3_kernel":  # <T, D, CAUSAL, STAMP>; the benchmark's head dim 64 keeps the short name bench.py uses
             tag = "" if vals[0] == "64" else f"D{vals[0]},"
             return f"{k}<{dt},{tag}{'causal' if vals[1] == '1' else 'full'}>"
         return f"{k}<{dt}>"
     if re.match(r"(?:void )?fa3_fwd3_kernel<bool _Accum, bool, E", name):  # <__bf16, true, false> mis-demangled
         return "fa3_fwd3_kernel<bf16,causal>"
+    if re.match(r"(?:void )?fa3_fwd4_kernel<", name):  # the benchmark launches <__bf16, true, 0, true>
+        return "fa3_fwd4_kernel<bf16,causal,k_prescaled>"
     m = re.match(r"(?:void )?(\w+_kernel)<bool _Accum, int, E(?:, (\d+))?", name)
     if m:  # rocprofv3 mis-demangles <__bf16, 1, ...>: only the gelu_tanh (ACT = 1) GEMMs of the benchmark show up so
         return f"{m.group(1)}<bf16,gelu_tanh>"
@@ -79,4 +83,9 @@ for p in glob.glob(f"{src}/pmc_sq/**/*counter_collection.csv", recursive=True):
             f.write(k + "\n")
             for c, v in sorted(cs.items()):
                 f.write(f"   {c:32s} mean={v:.4g}\n")
+            if cs.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in cs:
+                # matrix-pipe busy fraction: MFMA busy cycles (summed over SIMDs) / (kernel cycles x 1024 SIMDs);
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                busy = cs["SQ_VALU_MFMA_BUSY_CYCLES"] / (cs["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+                f.write(f"   {'=> matrix pipe busy':32s} {100 * busy:.1f} %\n")
 print(open("profiles/pmc_traffic.json").read() if traffic else "no traffic")
