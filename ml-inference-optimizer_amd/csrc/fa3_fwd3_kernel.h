@@ -63,6 +63,11 @@ struct Fa3Ops;
       else                                                                                                            \
         asm volatile("v_mfma_f32_32x32x16_" SUF " %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(kf), "n"(R), "n"(R + 3));   \
     }                                                                                                                 \
+    /* first k-step with the running reference as the C operand: S = K fragment . Q fragment + c (KPRE) */           \
+    template <int R>                                                                                                  \
+    static __device__ __forceinline__ void qk_c(f32x16_t& acc, const X8& kf, const f32x16_t& c) {                    \
+      asm volatile("v_mfma_f32_32x32x16_" SUF " %0, %1, a[%2:%3], %4" : "=&v"(acc) : "v"(kf), "n"(R), "n"(R + 3), "v"(c)); \
+    }                                                                                                                 \
     template <int RO>                                                                                                 \
     static __device__ __forceinline__ void lsum0(const X8& pf) {                                                      \
       asm volatile("v_mfma_f32_32x32x16_" SUF " a[224:239], a[%1:%2], %0, a[224:239]"                                 \
@@ -123,7 +128,15 @@ struct Fa3P2Role {
 // ABL (diagnostic build only, timing-only ablations with WRONG results -- what each piece of the tile loop costs):
 //   1 no scale-and-subtract / max in phase 2     2 no exp (P = converted S)     4 no row-sum MFMAs
 //   8 no DMA issue in the tile loop              16 no reference test / update  32 no edge masks
-template <typename T, int D, bool CAUSAL, bool STAMP = false, int ABL = 0>
+// KPRE (FaDev::k_prescaled; see fa3_fwd4_kernel.h): K carries softmax_scale * log2(e).  The reference enters the QK^T
+// product as the C operand of its first k-step (one 16-register tuple per query sub-tile), phase 2 loses its 64 v_fma +
+// 32 v_max3 per tile, and the rescale test is bit 14 of the OR of the tile's packed P words (move_ref below).
+template <typename T>
+struct Fa3Margin { static constexpr float value = 5.0f; };
+template <>
+struct Fa3Margin<_Float16> { static constexpr float value = 2.0f; };
+
+template <typename T, int D, bool CAUSAL, bool STAMP = false, int ABL = 0, bool KPRE = false>
 __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
   using X8 = typename DT<T>::x8;
   using X4 = typename DT<T>::x4;
@@ -190,6 +203,19 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
     // ---- running state per query sub-tile: m_i = reference the probabilities are taken against (exp2 domain; -inf =
     // no finite score yet, the reference is then 0), negref = -reference as used by the scale-and-subtract
     float m_i[QT], negref[QT], lcarry[QT];
+    // KPRE state per query sub-tile: ref = the reference subtracted through the C operand (0 while the row is fresh),
+    // nref16 = -ref in all 16 registers; orw = OR of the tile's packed P words; fresh_any is wave-uniform
+    float ref[QT] = {0.f, 0.f};
+    bool fresh[QT] = {true, true};
+    bool fresh_any = true;
+    uint32_t orw = 0u;
+    f32x16_t nref16[QT];
+    if constexpr (KPRE) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) nref16[qt][i] = 0.f;
+    }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       m_i[qt] = -INFINITY;
@@ -417,7 +443,8 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
         constexpr int j = decltype(J_)::value;
         {
           constexpr int ks = j >> 2, qt = (j & 3) >> 1, tt = j & 1;
-          OPS::template qk<FA3_A_Q + 4 * KS * qt + 4 * ks, ks == 0>(S[nb][qt][tt], kf[ks & 1][tt]);
+          if constexpr (KPRE && ks == 0) OPS::template qk_c<FA3_A_Q + 4 * KS * qt>(S[nb][qt][tt], kf[0][tt], nref16[qt]);
+          else OPS::template qk<FA3_A_Q + 4 * KS * qt + 4 * ks, ks == 0>(S[nb][qt][tt], kf[ks & 1][tt]);
           if constexpr ((j & 3) == 3 && ks + 2 < KS) read_k(IC(ks + 2));  // the ring slot of k-step ks is free again
         }
         if constexpr (DO_EXP) {
@@ -431,6 +458,7 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
             const float e2 = ex(S[cb][qt][s >> 1][base + 2]);
             const float e3 = ex(S[cb][qt][s >> 1][base + 3]);
             const uint32_t w0 = pack2<T>(e0, e1), w1 = pack2<T>(e2, e3);
+            if constexpr (KPRE) orw |= w0 | w1;
             asm volatile("" ::"v"(w0), "v"(w1));  // a use in THIS block: keeps the exp / cvt work from sinking to phase 2
             pfw[qt][s][2 * half + 0] = w0;
             pfw[qt][s][2 * half + 1] = w1;
@@ -489,7 +517,7 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
         }
         // scale-and-subtract + max of 4 scores per group, in the order the QK^T MFMAs of phase 1 finished writing
         // them: sub-tile qt = i / 8, 32-key half tt = (i / 4) & 1, registers 4 (i & 3) .. +3
-        if constexpr (ROLE::role(j) >= 1 && ROLE::role(j) <= 16 && !(DO_PV && (ABL & 1))) {
+        if constexpr (!KPRE && ROLE::role(j) >= 1 && ROLE::role(j) <= 16 && !(DO_PV && (ABL & 1))) {
           constexpr int i = ROLE::role(j) - 1, qt = i / 8, tt = (i / 4) & 1, r0 = 4 * (i & 3);
           // scalar fmas: this translation unit is compiled with -fno-slp-vectorize -- SLP packs adjacent scalar fmas into
           // v_pk_fma_f32, which costs more issue time beside MFMAs than the two scalar forms (MI355X_MICROARCH.md,
@@ -565,13 +593,83 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       }
     };
 
+    // ---- KPRE: move the reference of rows that need it (fresh rows that now see a finite score; rows with some P >= 2) for
+    // the tile whose scores sit in S[cb] at the OLD reference.  WHEN = 0: tile 0 of a pass (nothing exponentiated yet);
+    // WHEN = 1: after phase 1 -- also shift S[cb ^ 1] (the next tile's scores, produced with the old C operand) and recompute
+    // the tile's P.  Rare: not scheduled.
+    auto move_ref = [&](auto CB_, auto WHEN_) {
+      constexpr int cb = decltype(CB_)::value;
+      constexpr int WHEN = decltype(WHEN_)::value;
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results (asm) are read by the vector ALU next
+      fa2_for<QT>([&](auto QTI) {
+        constexpr int qt = decltype(QTI)::value;
+        float mxl = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mxl = fmaxf(mxl, fmaxf(S[cb][qt][0][i], S[cb][qt][1][i]));
+        const float mxr = fmaxf(mxl, other_half(mxl));
+        const bool need = fresh[qt] ? (mxr != -INFINITY) : (mxr >= 1.0f);
+        const float delta = need ? mxr + Fa3Margin<T>::value : 0.f;
+        const float alpha = (need && !fresh[qt]) ? fast_exp2(-delta) : 1.f;  // a fresh row's O and L are still zero
+        if (need) fresh[qt] = false;
+        ref[qt] += delta;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          S[cb][qt][0][i] -= delta;
+          S[cb][qt][1][i] -= delta;
+          if constexpr (WHEN != 0) {
+            S[cb ^ 1][qt][0][i] -= delta;
+            S[cb ^ 1][qt][1][i] -= delta;
+          }
+          nref16[qt][i] = -ref[qt];
+        }
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+          auto rescale = [&](auto KI) {
+            constexpr int k = decltype(KI)::value;
+            f32x4_t v[4] = {Fa2AccIO<k>::template read4<0>(), Fa2AccIO<k>::template read4<1>(),
+                            Fa2AccIO<k>::template read4<2>(), Fa2AccIO<k>::template read4<3>()};
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[gq][e] *= alpha;
+            Fa2AccIO<k>::template write4<0>(v[0]);
+            Fa2AccIO<k>::template write4<1>(v[1]);
+            Fa2AccIO<k>::template write4<2>(v[2]);
+            Fa2AccIO<k>::template write4<3>(v[3]);
+          };
+          fa2_for<DT_>([&](auto DTI) { rescale(IC(FA3_T_O + qt * DT_ + decltype(DTI)::value)); });
+          rescale(IC(FA3_T_L + qt));
+        }
+      });
+      if constexpr (WHEN == 1) {
+        orw = 0u;
+        fa2_for<16>([&](auto HU_) {
+          constexpr int hu = decltype(HU_)::value, u = hu >> 1, half = hu & 1, qt = u >> 2, s2 = u & 3;
+          constexpr int base = 8 * (s2 & 1) + 4 * half;
+          const float e0 = fast_exp2(S[cb][qt][s2 >> 1][base + 0]);
+          const float e1 = fast_exp2(S[cb][qt][s2 >> 1][base + 1]);
+          const float e2 = fast_exp2(S[cb][qt][s2 >> 1][base + 2]);
+          const float e3 = fast_exp2(S[cb][qt][s2 >> 1][base + 3]);
+          const uint32_t w0 = pack2<T>(e0, e1), w1 = pack2<T>(e2, e3);
+          orw |= w0 | w1;
+          pfw[qt][s2][2 * half + 0] = w0;
+          pfw[qt][s2][2 * half + 1] = w1;
+        });
+      }
+      fresh_any = __builtin_amdgcn_ballot_w64(fresh[0] || fresh[1]) != 0;
+      asm volatile("s_nop 7" ::: "memory");
+    };
+
     // ---- scores, masks, maximum and reference of tile 0
     if (n_w > 0) {
       phase1(IC(1), IC(0), smem, smem);
       if (is_edge(0)) mask_tile(IC(0), 0);
       else asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-      phase2(IC(0), IC(0), smem, 0);
-      update(IC(0));
+      if constexpr (KPRE) {
+        move_ref(IC(0), IC(0));
+      } else {
+        phase2(IC(0), IC(0), smem, 0);
+        update(IC(0));
+      }
     }
 
     // ---- tiles this wave computes (two per trip: the score buffers alternate), then the tiles it only helps to
@@ -588,7 +686,12 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       const char* kb_n = smem + ((t + 1) & 3) * SM::STAGE;
       const char* vb_c = smem + (t & 3) * SM::STAGE + SM::K_BYTES;
       const bool has_next = (t + 1 < n_w);
+      if constexpr (KPRE) orw = 0u;
       phase1(CB_, IC(1), kb_n, vb_c);
+      if constexpr (KPRE) {
+        // some P >= 2 (bit 14 of a packed 16-bit word; inf and NaN included), or a row still waiting for its first score
+        if (__builtin_amdgcn_ballot_w64((orw & 0x40004000u) != 0u) != 0 || fresh_any) move_ref(CB_, IC(1));
+      }
       if constexpr (STAMP) c2 = __builtin_amdgcn_s_memtime();
       if constexpr (!(ABL & 32))
         if (has_next && is_edge(t + 1)) mask_tile(IC(cb ^ 1), (t + 1) * FA_BN);
@@ -597,7 +700,7 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       dma_tile_base(t + 3);
       phase2(IC(cb ^ 1), IC(1), vb_c, t + 3);
       if constexpr (STAMP) c3 = __builtin_amdgcn_s_memtime();
-      if constexpr (!(ABL & 16))
+      if constexpr (!KPRE && !(ABL & 16))
         if (has_next) update(IC(cb ^ 1));
       if constexpr (STAMP) c4 = __builtin_amdgcn_s_memtime();
       land();
@@ -642,7 +745,7 @@ __global__ __launch_bounds__(256) void fa3_fwd3_kernel(const FaDev p) {
       const float inv = (l_tot > 0.f) ? fast_rcp(l_tot) : 0.f;
       if (q_ok[qt]) {
         if (p.lse != nullptr && h == 0) {
-          const float lse = (l_tot > 0.f) ? (m_i[qt] + fast_log2(l_tot)) * FA_LN2 : -INFINITY;
+          const float lse = (l_tot > 0.f) ? ((KPRE ? ref[qt] : m_i[qt]) + fast_log2(l_tot)) * FA_LN2 : -INFINITY;
           p.lse[((int64_t)b * p.H + head) * p.Sq + qrow[qt]] = lse;
         }
       }

@@ -59,16 +59,16 @@ static int launch_two(FaDev p, hipStream_t stream) {
 #endif
 
 // third structure (software-pipelined across KV tiles): no user mask
-template <bool CAUSAL>
+template <bool CAUSAL, bool KPRE = false>
 static int launch_three(FaDev p, hipStream_t stream) {
   p.nqblk = (p.Sq + FA3_BM - 1) / FA3_BM;
   p.qgrid = CAUSAL ? (p.nqblk + 1) / 2 : p.nqblk;
   const int grid = p.qgrid * p.B * p.H;
   const size_t smem = FA3_STAGES * FaSmem<FA_D>::STAGE;
-  auto kern = fa3_fwd3_kernel<FaT, FA_D, CAUSAL>;
+  auto kern = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, false, 0, KPRE>;
 #ifdef MIO_DIAG
 #if FA_D == 64 && FA_TYPE_ID == 0
-  if constexpr (CAUSAL) {  // timing-only ablations (tools/fa_ablate.py): mio_dbg_set(0, bits)
+  if constexpr (CAUSAL && !KPRE) {  // timing-only ablations (tools/fa_ablate.py): mio_dbg_set(0, bits)
     void (*ka)(const FaDev) = nullptr;
     switch (mio_dbg_get(0)) {
       case 1: ka = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, false, 1>; break;
@@ -93,7 +93,7 @@ static int launch_three(FaDev p, hipStream_t stream) {
   }
 #endif
   static const char* dbg_ptr = std::getenv("MIO_FA_DBG_PTR");  // in-kernel phase stamps (tools/fa_stamps.py)
-  if (dbg_ptr != nullptr) {
+  if (dbg_ptr != nullptr && !KPRE) {
     auto kd = fa3_fwd3_kernel<FaT, FA_D, CAUSAL, true>;
     p.mask = (const void*)std::strtoull(dbg_ptr, nullptr, 0);
     hipError_t ed = hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -186,11 +186,17 @@ int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t
   // keep fa3_fwd3, = 4 force fa3_fwd4 for non-causal launches too.
   {
     const bool plain = mask_kind == MIO_MASK_NONE && p.Sq > 128 && span32 && p.o != nullptr && p.o_acc == nullptr && !p.carry_in;
-    if (p.k_prescaled) {  // (mio_fa3_fwd has checked mio_fa3_k_prescaled_ok: plain holds)
-      if (!plain) return mio_fail("fa3_fwd: k_prescaled launch outside the fa3_fwd4 path");
-      return causal ? launch_four<true, true>(p, stream) : launch_four<false, true>(p, stream);
+    // k_prescaled (mio_fa3_fwd has checked mio_fa3_k_prescaled_ok): causal -> fa3_fwd4 KPRE, non-causal -> fa3_fwd3 KPRE
+    // (same box, interleaved, B8 S4096 H16: causal 0.3355 / 0.3372 ms fwd4 / fwd3, non-causal 0.6255 / 0.5946)
+    if (p.k_prescaled && plain) {
+      bool four_k = causal != 0;
+#ifdef MIO_DIAG
+      if (mio_dbg_get(1) == 3) four_k = false;  // A/B switches
+      if (mio_dbg_get(1) == 4) four_k = true;
+#endif
+      if (four_k) return causal ? launch_four<true, true>(p, stream) : launch_four<false, true>(p, stream);
     }
-    bool four = plain && causal && fa_impl() == 0;
+    bool four = plain && causal && fa_impl() == 0 && !p.k_prescaled;
 #ifdef MIO_DIAG
     if (mio_dbg_get(1) == 3) four = false;
     if (plain && (fa_impl() == 4 || mio_dbg_get(1) == 4)) four = true;
@@ -201,6 +207,15 @@ int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t
 #endif
   }
 #endif
+  if (p.k_prescaled) {  // head dim 65 .. 96 (and the diagnostic A/B at 64): fa3_fwd3's KPRE form.  Not at 128: the two
+                         // reference tuples (32 VGPRs) do not fit beside the score / P / fragment registers there -- hipcc
+                         // parks values in accumulator registers the kernel owns (tools/check_agpr.py catches it)
+#if FA_D < 128
+    if (mask_kind == MIO_MASK_NONE && p.Sq > 128 && span32 && p.o != nullptr && p.o_acc == nullptr && !p.carry_in)
+      return causal ? launch_three<true, true>(p, stream) : launch_three<false, true>(p, stream);
+#endif
+    return mio_fail("fa3_fwd: k_prescaled launch outside the kernels that support it");
+  }
   if ((fa_impl() == 3 || fa_impl() == 0) && mask_kind == MIO_MASK_NONE && p.Sq > 128 && span32)
     return causal ? launch_three<true>(p, stream) : launch_three<false>(p, stream);
 #ifdef MIO_DIAG

@@ -151,9 +151,17 @@ class RingCrossAttention(RingAttention):
         xkv = key_value_states if key_value_states.dtype == dt else key_value_states.to(dt)
         c = self._cast
         q = self._heads(linear(xq, self.q_proj, c, dt))
-        k = self._heads(linear(xkv, self.k_proj, c, dt))
+        # where the kernels allow it the K projection's epilogue hands over K * softmax_scale * log2(e) (one rounding) and
+        # the attention kernel drops its per-score multiply (ops.fa3_fwd k_prescaled)
+        B, Sq, d = xq.shape
+        Sk = xkv.shape[1]
+        kpre = (attention_mask is None and d % 128 == 0 and d % 32 == 0
+                and ops.fa3_k_prescaled_ok(B, Sq, Sk, self.num_attention_heads, self.head_dim, d, d)
+                and ops.blocked_weight_ok(B * Sk, d, d) and ops.col_scale_ok(B * Sk, d, d))
+        cs = (0, d, self.scale * 1.4426950408889634) if kpre else None
+        k = self._heads(linear(xkv, self.k_proj, c, dt, col_scale=cs))
         v = self._heads(linear(xkv, self.v_proj, c, dt))
-        ctx = ops.ring_attention_forward(q, k, v, attention_mask)
+        ctx = ops.ring_attention_forward(q, k, v, attention_mask, k_prescaled=kpre)
         r = None if residual is None else (residual if residual.dtype == dt else residual.to(dt))
         out = linear(ctx, self.out_proj, c, dt, residual=r)
         return out if out.dtype == in_dtype else out.to(in_dtype)

@@ -199,7 +199,7 @@ def fa3_fwd(
     p.q_offset, p.k_offset, p.softmax_scale = int(q_offset), int(k_offset), scale
     if k_prescaled:
         if not lib.mio_fa3_k_prescaled_ok(C.byref(p)):
-            raise ValueError("k_prescaled is only supported for head_dim <= 64, no mask, no (o_acc, lse) carry, Sq > 128")
+            raise ValueError("k_prescaled is only supported for head_dim <= 96, no mask, no (o_acc, lse) carry, Sq > 128")
         p.k_prescaled = 1
     check(lib.mio_fa3_fwd(C.byref(p), _stream()))
     if return_lse:
@@ -209,7 +209,7 @@ def fa3_fwd(
 
 def fa3_k_prescaled_ok(B: int, Sq: int, Sk: int, H: int, D: int, k_row_stride: int, v_row_stride: int) -> bool:
     """True iff fa3_fwd(..., k_prescaled=True) is available for a plain (no mask, no carry) launch of this geometry."""
-    return D <= 64 and Sq > 128 and Sk * k_row_stride * 2 < (1 << 32) and Sk * v_row_stride * 2 < (1 << 32)
+    return D <= 96 and Sq > 128 and Sk * k_row_stride * 2 < (1 << 32) and Sk * v_row_stride * 2 < (1 << 32)
 
 
 def _canon_mask4(mask: torch.Tensor) -> torch.Tensor:
@@ -254,16 +254,19 @@ def flash_attention(
 
 
 def ring_attention_forward(
-    query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attention_mask: Optional[torch.Tensor] = None
+    query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+    k_prescaled: bool = False,
 ) -> torch.Tensor:
     """Drop-in for triton_ring_attention_forward (attention_kernels.py:909-1005; fallback :1520-1591):
-    q/k/v [B,H,S,D] head-major, additive mask [B,1|H,Sq,Sk]; returns [B,Sq,H*D]."""
+    q/k/v [B,H,S,D] head-major, additive mask [B,1|H,Sq,Sk]; returns [B,Sq,H*D].
+    k_prescaled (not in the reference): see fa3_fwd."""
     if query.dim() != 4:
         raise ValueError(f"Expected 4D tensors, got {query.shape}")
     B, H, Sq, D = query.shape
     out = torch.empty(B, Sq, H, D, dtype=query.dtype, device=query.device)
     # write straight into the [B,Sq,H*D] result: give the kernel a head-major VIEW of it
-    fa3_fwd(query, key, value, layout="bhsd", additive_mask=attention_mask, out=out.permute(0, 2, 1, 3))
+    fa3_fwd(query, key, value, layout="bhsd", additive_mask=attention_mask, out=out.permute(0, 2, 1, 3),
+            k_prescaled=k_prescaled)
     return out.view(B, Sq, H * D)
 
 

@@ -393,3 +393,37 @@ def test_c5_cross_block():
 
     _record("c5_cross_block B2 Sq4096 Sk1101 d1280 H16 I5120", y.view(-1, d), chain(torch.float32).view(-1, d),
             chain(torch.bfloat16).view(-1, d))
+
+
+def test_c5_cross_attention_k_prescaled():
+    """RingCrossAttention at a size where the K projection runs the persistent GEMM: its epilogue hands over
+    K * softmax_scale * log2(e) and the Dh 80 non-causal launch takes fa3_fwd3's k_prescaled form."""
+    from mio.kernels.attention.ring_attention import RingAttentionConfig, RingCrossAttention
+    from mio import ops
+    B, S, d, H = 4, 4096, C5["d"], C5["H"]
+    D = d // H
+    assert ops.col_scale_ok(B * S, d, d) and ops.fa3_k_prescaled_ok(B, S, S, H, D, d, d)
+    torch.manual_seed(2)
+    att = RingCrossAttention(d, H, RingAttentionConfig(precision="bf16"))
+    with torch.no_grad():
+        for m in att.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.weight.copy_(torch.randn(m.weight.shape) * 0.03)
+                m.bias.copy_(torch.randn(m.bias.shape) * 0.02)
+    att = att.to(device=DEV, dtype=torch.bfloat16).eval()
+    x, = _c2_inputs(50, (B, S, d))
+    ctx_in, = _c2_inputs(51, (B, S, d))
+    with torch.no_grad():
+        y = att(x, ctx_in, residual=x)
+
+    def chain(dt):
+        f = lambda t: t.to(dt)
+        with torch.no_grad():
+            q = F.linear(f(x), f(att.q_proj.weight), f(att.q_proj.bias)).view(B, S, H, D)
+            k = F.linear(f(ctx_in), f(att.k_proj.weight), f(att.k_proj.bias)).view(B, S, H, D)
+            v = F.linear(f(ctx_in), f(att.v_proj.weight), f(att.v_proj.bias)).view(B, S, H, D)
+            c = (_attention_truth(q, k, v, False) if dt == torch.float32 else _attention_ref16(q, k, v, False)).to(dt)
+            return F.linear(c.view(B, S, d), f(att.out_proj.weight), f(att.out_proj.bias)) + f(x)
+
+    _record("c5_cross_attention_module k_prescaled B4 Sq4096 Sk4096 d1280 H16", y.view(-1, d), chain(torch.float32).view(-1, d),
+            chain(torch.bfloat16).view(-1, d))
