@@ -135,7 +135,7 @@ def kernel_rooflines(model, x, iters=10):
     o3, o1 = torch.empty_like(qkv), torch.empty_like(att)
     out = {}
     t = _events_ms(lambda: ops.fa3_fwd(q, k, v, causal=True, k_prescaled=kpre), iters)
-    out["fa3_fwd4_kernel<bf16,causal" + (",k_prescaled>" if kpre else ">")] = dict(ms=t, launches=1, flops=2.0 * B * S * (S + 1) * d)
+    out["fa3_fwd5_kernel<bf16,causal>" if kpre else "fa3_fwd4_kernel<bf16,causal>"] = dict(ms=t, launches=1, flops=2.0 * B * S * (S + 1) * d)
 
     t = _events_ms(lambda: ops.gemm_bias_act(ln1, wqkv, bqkv, out=o3, w_blocked=wqkv_b, col_scale=cs), iters)
     out["gemm4w16p_kernel<bf16,none>"] = dict(ms=t, launches=1, flops=2.0 * M * d * 3 * d)  # qkv

@@ -1,0 +1,366 @@
+// FlashAttention forward, fifth structure: fa3_fwd4_kernel's two-waves-per-SIMD skeleton on v_mfma_f32_16x16x32 tiles
+// (head dim <= 64, k_prescaled launches only: K carries softmax_scale * log2(e), fa3_fwd4_kernel.h KPRE).
+//
+// Why: the attention kernels are bound by the power cap, so what counts is energy per tile.
+//   * On random operands the chip sustains ~1.2 x the FLOP/s on 16x16x32 that it does on 32x32x16 (tools/micro/
+//     mfma_peak.hip: 1.88 vs 1.53 PFLOP/s, same cycles per FLOP, higher clock).
+//   * The row sum "ones . P^T" is one MFMA per (16 queries, 32 keys): 4 of 36 MFMAs of 16 cycles per wave-tile instead of
+//     4 of 20 of 32 cycles -- 1/9 of the matrix-pipe time instead of 1/5.
+// The swapped product carries over to the 16x16 shape:
+//   S^T tile (16 keys x 16 queries) = K tile (A: lane (r, g) = K[key 16 kt + r][d 32 ds + 8 g .. +7], one ds_read_b128)
+//                                     . Q^T (B: lane (c, g) = Q[query 16 qg + c][d 32 ds + 8 g .. +7]); accumulator: query
+//                                     c on the lane, keys 16 kt + 4 g + i in registers i = 0..3;
+//   P^T as the B operand of O^T += V^T . P^T needs k = 8 g + j on lane group g: the exp'd registers of key tiles 2 s and
+//     2 s + 1 ARE that fragment for the 32-key step s if k <-> key is read as j < 4: 32 s + 4 g + j, j >= 4: 32 s + 16 + 4 g
+//     + (j - 4) -- the contraction order is free as long as the A operand uses the same map;
+//   V^T tile (A: 16 d rows x 32 keys) in that map = two ds_read_b64_tr_b16 of 4 consecutive keys x 16 d from a ROW-MAJOR V
+//     image (lane group g: keys 32 s (+16) + 4 g .., lane i of the group receives column d = 16 dt + i).
+// LDS images (both filled by DMA, swizzle on the per-lane SOURCE address): K rows of 128 B with chunk c at c ^ ((row >> 1) &
+// 7) as in fwd4 (conflict-free ds_read_b128 for this lane -> (row, chunk) map too); V rows of 128 B with the 32-byte block b
+// at b ^ ((row >> 1) & 3) (the 8 rows of a half-wave's transposed read then cover 8 different 32-byte blocks of the 256-byte
+// bank row).
+#pragma once
+#include "fa3_fwd4_kernel.h"
+
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
+  using X8 = typename DT<T>::x8;
+  using X4 = typename DT<T>::x4;
+  constexpr int NKT = 4, NQG = 2, NDS = 2, NDT = 4, NS = 2, UPW = 2;
+#define IC(N) std::integral_constant<int, (N)> {}
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, g = lane >> 4;
+
+  int bh, qi;
+  {
+    const int id = blockIdx.x;
+    if (p.xcd_remap & 1) {
+      const int xcd = id & 7, slot = id >> 3;
+      bh = (slot / p.qgrid) * 8 + xcd;
+      qi = slot % p.qgrid;
+    } else {
+      bh = id / p.qgrid;
+      qi = id % p.qgrid;
+    }
+  }
+  const int b = bh / p.H, head = bh % p.H;
+  const int kvh = head / (p.H / p.Hkv);
+  const X8 ones = __builtin_bit_cast(X8, (u32x4_t){pack2<T>(1.f, 1.f), pack2<T>(1.f, 1.f), pack2<T>(1.f, 1.f), pack2<T>(1.f, 1.f)});
+
+  // per-lane LDS read offsets
+  int k_rd[NDS];  // K fragment (kt, ds): row 16 kt + c16, chunk 4 ds + g at position (4 ds + g) ^ ((c16 >> 1) & 7)
+#pragma unroll
+  for (int ds = 0; ds < NDS; ++ds) k_rd[ds] = c16 * 128 + 16 * ((4 * ds + g) ^ ((c16 >> 1) & 7));
+  int v_rd[NDT];  // V fragment (dt, s, hf): row 32 s + 16 hf + 4 g + q, 32-byte block dt ^ x, 8 bytes at 8 p2
+  {
+    const int q = c16 >> 2, p2 = c16 & 3, x = ((4 * g + q) >> 1) & 3;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) v_rd[dt] = FA4_KBYTES + (4 * g + q) * 128 + ((dt ^ x) * 32) + 8 * p2;
+  }
+
+  const T* kbase = (const T*)p.k + b * p.ks_b + kvh * p.ks_h;
+  const T* vbase = (const T*)p.v + b * p.vs_b + kvh * p.vs_h;
+  const int d_chunks = p.D >> 3;
+  const int ks2 = (int)p.ks_s * 2, vs2 = (int)p.vs_s * 2;
+  const int last_tile = (p.Sk - 1) >> 6, last_row = (p.Sk - 1) & (FA_BN - 1);
+  // DMA: wave w moves rows 8 w .. 8 w + 7 of the K tile and of the V tile (one 1-KiB unit each)
+  int offk, offkl, offv, offvl;
+  {
+    const int row = 8 * wave + (lane >> 3), pos = lane & 7;
+    const int rowl = row < last_row ? row : last_row;
+    int kc = pos ^ ((row >> 1) & 7);
+    kc = kc < d_chunks ? kc : d_chunks - 1;
+    offk = row * ks2 + 16 * kc;
+    offkl = rowl * ks2 + 16 * kc;
+    int vc = (((pos >> 1) ^ ((row >> 1) & 3)) << 1) | (pos & 1);
+    vc = vc < d_chunks ? vc : d_chunks - 1;
+    offv = row * vs2 + 16 * vc;
+    offvl = rowl * vs2 + 16 * vc;
+  }
+
+  const int npass = (CAUSAL && (p.nqblk - 1 - qi) != qi) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int qblk = CAUSAL ? (pass == 0 ? p.nqblk - 1 - qi : qi) : qi;
+    const int q0 = qblk * FA4_BM;
+    const int wrow0 = q0 + wave * 32;
+    int qrow[NQG];
+    bool q_ok[NQG];
+#pragma unroll
+    for (int qg = 0; qg < NQG; ++qg) {
+      qrow[qg] = wrow0 + 16 * qg + c16;
+      q_ok[qg] = qrow[qg] < p.Sq;
+    }
+
+    int n_tiles, n_w;
+    if (CAUSAL) {
+      int kmax = q0 + FA4_BM - 1 + p.q_offset - p.k_offset;
+      if (kmax > p.Sk - 1) kmax = p.Sk - 1;
+      n_tiles = kmax < 0 ? 0 : kmax / FA_BN + 1;
+      int kw = wrow0 + 31 + p.q_offset - p.k_offset;
+      if (kw > p.Sk - 1) kw = p.Sk - 1;
+      n_w = kw < 0 ? 0 : kw / FA_BN + 1;
+    } else {
+      n_tiles = (p.Sk + FA_BN - 1) / FA_BN;
+      n_w = n_tiles;
+    }
+    const int n_tiles_dma = n_tiles > 0 ? n_tiles : 1;
+    int klim[NQG], lim0 = p.Sk - 1;
+#pragma unroll
+    for (int qg = 0; qg < NQG; ++qg) {
+      klim[qg] = p.Sk - 1;
+      if (CAUSAL) {
+        const int c = qrow[qg] + p.q_offset - p.k_offset;
+        klim[qg] = c < klim[qg] ? c : klim[qg];
+      }
+    }
+    if (CAUSAL) {
+      const int c0 = wrow0 + p.q_offset - p.k_offset;
+      lim0 = c0 < lim0 ? c0 : lim0;
+    }
+    const int first_edge = (lim0 + 1) / FA_BN;
+
+    auto stage_dma = [&](int tile_) {
+      const int tile = tile_ < n_tiles_dma ? tile_ : n_tiles_dma - 1;
+      const uint32_t ko = __builtin_amdgcn_readfirstlane((uint32_t)(tile * FA_BN) * (uint32_t)ks2);
+      const uint32_t vo = __builtin_amdgcn_readfirstlane((uint32_t)(tile * FA_BN) * (uint32_t)vs2);
+      const char* kb = (const char*)kbase + ko;
+      const char* vb = (const char*)vbase + vo;
+      const bool lastt = (tile == last_tile);
+      const uint32_t lds = (uint32_t)(size_t)((MIO_LDS char*)(smem + (tile_ & (FA4_STAGES - 1)) * FA4_STAGE)) + 1024 * wave;
+      const int ok_ = lastt ? offkl : offk, ov_ = lastt ? offvl : offv;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds), "v"(ok_), "s"(kb) : "memory", "m0");
+      asm volatile("s_add_i32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                   :
+                   : "s"(lds), "n"(FA4_KBYTES), "v"(ov_), "s"(vb)
+                   : "memory", "m0", "scc");
+    };
+
+    __syncthreads();  // the previous pass is done with every LDS stage
+    stage_dma(0);
+    stage_dma(1);
+    stage_dma(2);
+
+    // ---- Q fragments (B operand: lane (c16, g) holds Q[qrow[qg]][32 ds + 8 g .. +7]); rows past Sq / chunks past D are zero
+    X8 qf[NQG][NDS];
+#pragma unroll
+    for (int qg = 0; qg < NQG; ++qg) {
+      const T* qp = (const T*)p.q + b * p.qs_b + head * p.qs_h + (int64_t)(q_ok[qg] ? qrow[qg] : 0) * p.qs_s;
+#pragma unroll
+      for (int ds = 0; ds < NDS; ++ds) {
+        const int d0 = 32 * ds + 8 * g;
+        u32x4_t raw = *(const u32x4_t*)(qp + (d0 < p.D ? d0 : 0));
+        const uint32_t keep = (q_ok[qg] && d0 < p.D) ? 0xffffffffu : 0u;
+        raw[0] &= keep; raw[1] &= keep; raw[2] &= keep; raw[3] &= keep;
+        qf[qg][ds] = __builtin_bit_cast(X8, raw);
+      }
+    }
+    f32x4_t O[NDT][NQG], L[NQG];
+#pragma unroll
+    for (int qg = 0; qg < NQG; ++qg) {
+      L[qg] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) O[dt][qg] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    // per query group: ref = the reference subtracted through the C operand (running maximum at the last move + margin; 0
+    // while the row is fresh), nref4 = -ref in all four registers; orw = OR of the tile's packed P words
+    float ref[NQG] = {0.f, 0.f};
+    bool fresh[NQG] = {true, true};
+    bool fresh_any = true;
+    uint32_t orw = 0u;
+    f32x4_t nref4[NQG] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW) : "memory");  // tiles 0 and 1 have landed, tile 2 may still fly
+    __syncthreads();
+
+    f32x4_t S[2][NKT][NQG];  // score tiles: buffer (t & 1), 16-key tile, query group
+    u32x4_t pfw[NS][NQG];    // P^T fragments: 32-key step s, query group
+    X8 vf[2];                // V^T fragments: ring of two
+
+    auto read_k = [&](X8 (&kf)[NKT][NDS], const char* kb) {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) kf[kt][ds] = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + 2048 * kt + k_rd[ds]));
+    };
+    auto qk_one = [&](auto NB_, auto J_, X8 (&kf)[NKT][NDS]) {  // MFMA j of the 16: kt = j / 4, ds = (j / 2) % 2, qg = j % 2
+      constexpr int nb = decltype(NB_)::value, j = decltype(J_)::value, kt = j >> 2, ds = (j >> 1) & 1, qg = j & 1;
+      if constexpr (ds == 0) S[nb][kt][qg] = DT<T>::mfma16(kf[kt][0], qf[qg][0], nref4[qg]);
+      else S[nb][kt][qg] = DT<T>::mfma16(kf[kt][1], qf[qg][1], S[nb][kt][qg]);
+    };
+    // one exp / convert unit: the 4 scores of (key tile kt, query group qg) -> two words of P^T fragment (kt / 2, qg)
+    auto exp_unit = [&](auto CB_, auto U_) {
+      constexpr int cb = decltype(CB_)::value, u = decltype(U_)::value, kt = u >> 1, qg = u & 1;
+      const float e0 = fast_exp2(S[cb][kt][qg][0]);
+      const float e1 = fast_exp2(S[cb][kt][qg][1]);
+      const float e2 = fast_exp2(S[cb][kt][qg][2]);
+      const float e3 = fast_exp2(S[cb][kt][qg][3]);
+      const uint32_t w0 = pack2<T>(e0, e1), w1 = pack2<T>(e2, e3);
+      orw |= w0 | w1;
+      asm volatile("" ::"v"(w0), "v"(w1));  // a use in THIS step: keeps the work from sinking to its consumer in phase 2
+      pfw[kt >> 1][qg][2 * (kt & 1) + 0] = w0;
+      pfw[kt >> 1][qg][2 * (kt & 1) + 1] = w1;
+    };
+    auto read_v = [&](const char* vb, auto F_) {  // fragment f = 4 s + dt into vf[f & 1]
+      constexpr int f = decltype(F_)::value, s = f >> 2, dt = f & 3;
+      const X4 lo = DT<T>::ds_read_tr(vb + 4096 * s + v_rd[dt]);
+      const X4 hi = DT<T>::ds_read_tr(vb + 4096 * s + 2048 + v_rd[dt]);
+      X8 x;
+      x[0] = lo[0]; x[1] = lo[1]; x[2] = lo[2]; x[3] = lo[3];
+      x[4] = hi[0]; x[5] = hi[1]; x[6] = hi[2]; x[7] = hi[3];
+      vf[f & 1] = x;
+    };
+    // ---- phase 1: S[cb ^ 1] = scores of the next tile (K image at kb) minus the reference (C operand)  ||  P = exp2(S[cb]).
+    // All eight K fragments are requested first, one exp unit runs under their latency, then two MFMAs + one unit per step.
+    auto phase1 = [&](auto CB_, auto DO_EXP_, const char* kb, const char* vb) {
+      constexpr int cb = decltype(CB_)::value, nb = cb ^ 1;
+      constexpr bool DO_EXP = decltype(DO_EXP_)::value != 0;
+      X8 kf[NKT][NDS];
+      read_k(kf, kb);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DO_EXP) {
+        exp_unit(CB_, IC(0));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      fa2_for<8>([&](auto ST_) {
+        constexpr int st = decltype(ST_)::value;
+        qk_one(IC(nb), IC(2 * st), kf);
+        qk_one(IC(nb), IC(2 * st + 1), kf);
+        if constexpr (DO_EXP && st < 7) exp_unit(CB_, IC(st + 1));
+        if constexpr (DO_EXP && st == 5) read_v(vb, IC(0));  // the first V fragment of phase 2, early
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    // ---- phase 2: O^T += V^T . P^T, L += ones . P^T (V image at vb): 10 steps of two MFMAs (8 V fragments x 2 query groups,
+    // the row sums behind each 32-key step); the next V fragment is requested one step ahead
+    auto phase2 = [&](const char* vb) {
+      fa2_for<NS>([&](auto S_) {
+        constexpr int s = decltype(S_)::value;
+        fa2_for<NDT>([&](auto DT_I) {
+          constexpr int dt = decltype(DT_I)::value, f = 4 * s + dt;
+          O[dt][0] = DT<T>::mfma16(vf[f & 1], __builtin_bit_cast(X8, pfw[s][0]), O[dt][0]);
+          O[dt][1] = DT<T>::mfma16(vf[f & 1], __builtin_bit_cast(X8, pfw[s][1]), O[dt][1]);
+          if constexpr (f + 1 < 8) read_v(vb, IC(f + 1));
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        L[0] = DT<T>::mfma16(ones, __builtin_bit_cast(X8, pfw[s][0]), L[0]);
+        L[1] = DT<T>::mfma16(ones, __builtin_bit_cast(X8, pfw[s][1]), L[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    // masks of an edge tile on S[nb]; first key kv0n.  Key kv0n + 16 kt + 4 g + i is visible to query group qg's row iff <= klim
+    auto mask_tile = [&](auto NB_, int kv0n) {
+      constexpr int nb = decltype(NB_)::value;
+#pragma unroll
+      for (int qg = 0; qg < NQG; ++qg) {
+        const int thr = klim[qg] - kv0n - 4 * g;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (16 * kt + i > thr) S[nb][kt][qg][i] = -INFINITY;
+      }
+    };
+    // move the reference of rows that need it for the tile whose scores sit in S[cb] at the OLD reference (fa3_fwd4 KPRE).
+    // WHEN = 0: tile 0 of a pass; 1: after phase 1 -- also shift S[cb ^ 1] and recompute the tile's P.  Rare.
+    auto move_ref = [&](auto CB_, auto WHEN_) {
+      constexpr int cb = decltype(CB_)::value;
+      constexpr int WHEN = decltype(WHEN_)::value;
+#pragma unroll
+      for (int qg = 0; qg < NQG; ++qg) {
+        float mxl = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mxl = fmaxf(mxl, S[cb][kt][qg][i]);
+        mxl = fmaxf(mxl, __shfl_xor(mxl, 16, 64));  // the four lanes c16 + 16 g of a query hold its 64 keys
+        const float mxr = fmaxf(mxl, __shfl_xor(mxl, 32, 64));
+        const bool need = fresh[qg] ? (mxr != -INFINITY) : (mxr >= 1.0f);
+        const float delta = need ? mxr + Fa4Margin<T>::value : 0.f;
+        const float alpha = (need && !fresh[qg]) ? fast_exp2(-delta) : 1.f;
+        if (need) fresh[qg] = false;
+        ref[qg] += delta;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            S[cb][kt][qg][i] -= delta;
+            if constexpr (WHEN != 0) S[cb ^ 1][kt][qg][i] -= delta;
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          nref4[qg][i] = -ref[qg];
+          L[qg][i] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) O[dt][qg][i] *= alpha;
+        }
+      }
+      if constexpr (WHEN == 1) {
+        orw = 0u;
+        fa2_for<8>([&](auto U_) { exp_unit(CB_, U_); });
+      }
+      fresh_any = __builtin_amdgcn_ballot_w64(fresh[0] || fresh[1]) != 0;
+    };
+    auto is_edge = [&](int t) -> bool { return t >= first_edge; };
+    auto land = [&]() {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW) : "memory");
+      __syncthreads();
+    };
+    auto stg = [&](int tile) -> const char* { return smem + (tile & (FA4_STAGES - 1)) * FA4_STAGE; };
+
+    int t = 0;
+    // ---- scores, masks and reference of tile 0
+    if (n_w > 0) {
+      phase1(IC(1), IC(0), stg(0), stg(0));
+      if (is_edge(0)) mask_tile(IC(0), 0);
+      move_ref(IC(0), IC(0));
+    }
+    auto iter = [&](int t, auto CB_) {
+      constexpr int cb = decltype(CB_)::value;
+      const bool has_next = (t + 1 < n_w);
+      orw = 0u;
+      phase1(CB_, IC(1), stg(t + 1), stg(t));
+      if (__builtin_amdgcn_ballot_w64((orw & 0x40004000u) != 0u) != 0 || fresh_any) move_ref(CB_, IC(1));
+      if (has_next && is_edge(t + 1)) mask_tile(IC(cb ^ 1), (t + 1) * FA_BN);
+      stage_dma(t + 3);
+      phase2(stg(t));
+      land();
+    };
+    for (; t + 1 < n_w; t += 2) {
+      iter(t, IC(0));
+      iter(t + 1, IC(1));
+    }
+    if (t < n_w) {
+      iter(t, IC(0));
+      ++t;
+    }
+    for (; t < n_tiles; ++t) {
+      stage_dma(t + 3);
+      land();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: lane (c16, g) holds O[query qrow[qg]][d = 16 dt + 4 g + i]: one 8-byte store per (dt, qg)
+#pragma unroll
+    for (int qg = 0; qg < NQG; ++qg) {
+      const float l_tot = L[qg][0];
+      const float inv = (l_tot > 0.f) ? fast_rcp(l_tot) : 0.f;
+      if (q_ok[qg] && p.lse != nullptr && g == 0) {
+        const float lse = (l_tot > 0.f) ? (ref[qg] + fast_log2(l_tot)) * FA_LN2 : -INFINITY;
+        p.lse[((int64_t)b * p.H + head) * p.Sq + qrow[qg]] = lse;
+      }
+      T* op = (T*)p.o + b * p.os_b + head * p.os_h + (int64_t)(q_ok[qg] ? qrow[qg] : 0) * p.os_s;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int d0 = 16 * dt + 4 * g;
+        const u32x2_t w = {pack2<T>(O[dt][qg][0] * inv, O[dt][qg][1] * inv), pack2<T>(O[dt][qg][2] * inv, O[dt][qg][3] * inv)};
+        if (q_ok[qg] && d0 < p.D) *(u32x2_t*)(op + d0) = w;
+      }
+    }
+  }  // pass
+#undef IC
+}

@@ -8,6 +8,7 @@
 #include "fa3_fwd3_kernel.h"
 #if FA_D == 64
 #include "fa3_fwd4_kernel.h"
+#include "fa3_fwd5_kernel.h"
 #endif
 
 #if FA_TYPE_ID == 0
@@ -159,6 +160,25 @@ static int launch_four(FaDev p, hipStream_t stream) {
 }
 #endif
 
+// fifth structure (fa3_fwd4's skeleton on 16x16x32 MFMA tiles): k_prescaled launches, head dim <= 64
+#if FA_D == 64
+template <bool CAUSAL>
+static int launch_five(FaDev p, hipStream_t stream) {
+  p.nqblk = (p.Sq + FA4_BM - 1) / FA4_BM;
+  p.qgrid = CAUSAL ? (p.nqblk + 1) / 2 : p.nqblk;
+  const int grid = p.qgrid * p.B * p.H;
+  void (*kern)(const FaDev) = fa3_fwd5_kernel<FaT, CAUSAL>;
+  static std::once_flag once;
+  static hipError_t ea = hipSuccess;
+  std::call_once(once, [&] { ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, FA4_SMEM); });
+  if (ea != hipSuccess) return mio_fail(std::string("fa3_fwd5: hipFuncSetAttribute: ") + hipGetErrorString(ea));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), FA4_SMEM, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("fa3_fwd5 launch: ") + hipGetErrorString(e));
+  return 0;
+}
+#endif
+
 #ifdef MIO_DIAG
 static int fa_impl() {  // MIO_FA_IMPL=1 / 2 / 3 force one structure for A/B runs (0 = the rule in fa3_launch)
   static const int v = [] {
@@ -186,15 +206,18 @@ int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t
   // keep fa3_fwd3, = 4 force fa3_fwd4 for non-causal launches too.
   {
     const bool plain = mask_kind == MIO_MASK_NONE && p.Sq > 128 && span32 && p.o != nullptr && p.o_acc == nullptr && !p.carry_in;
-    // k_prescaled (mio_fa3_fwd has checked mio_fa3_k_prescaled_ok): causal -> fa3_fwd4 KPRE, non-causal -> fa3_fwd3 KPRE
-    // (same box, interleaved, B8 S4096 H16: causal 0.3355 / 0.3372 ms fwd4 / fwd3, non-causal 0.6255 / 0.5946)
+    // k_prescaled (mio_fa3_fwd has checked mio_fa3_k_prescaled_ok), head dim <= 64: fa3_fwd5 (16x16x32 MFMA tiles).  Same
+    // box, interleaved, B8 S4096 H16 bf16: causal 0.3047 ms vs 0.3305 fa3_fwd4 KPRE / 0.3401 fa3_fwd3 KPRE / 0.3570 fa3_fwd3;
+    // non-causal 0.5494 vs 0.6162 / 0.5862 / 0.6273.  Diagnostic build: mio_dbg_set(1, 3 | 4) select the other KPRE forms.
     if (p.k_prescaled && plain) {
-      bool four_k = causal != 0;
+      int which = 5;
 #ifdef MIO_DIAG
-      if (mio_dbg_get(1) == 3) four_k = false;  // A/B switches
-      if (mio_dbg_get(1) == 4) four_k = true;
+      if (mio_dbg_get(1) == 3 || mio_dbg_get(1) == 4) which = mio_dbg_get(1);
 #endif
-      if (four_k) return causal ? launch_four<true, true>(p, stream) : launch_four<false, true>(p, stream);
+      if (which == 5) return causal ? launch_five<true>(p, stream) : launch_five<false>(p, stream);
+#ifdef MIO_DIAG
+      if (which == 4) return causal ? launch_four<true, true>(p, stream) : launch_four<false, true>(p, stream);
+#endif
     }
     bool four = plain && causal && fa_impl() == 0 && !p.k_prescaled;
 #ifdef MIO_DIAG

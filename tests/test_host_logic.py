@@ -294,7 +294,7 @@ def test_fwd3_accumulator_registers_untouched_by_compiler(tmp_path, type_id, D):
 
 
 def test_fwd4_two_waves_per_simd_fits_without_spills(tmp_path):
-    """fa3_fwd4_kernel runs two waves per SIMD: 256 registers per wave.  It must fit them without scratch (a staggered
+    """fa3_fwd4_kernel / fa3_fwd5_kernel run two waves per SIMD: 256 registers per wave.  It must fit them without scratch (a staggered
     variant that did not fit ran 60 % slower) -- check the ISA metadata of both dtypes' causal instantiation."""
     import shutil
     import subprocess
@@ -309,8 +309,8 @@ def test_fwd4_two_waves_per_simd_fits_without_spills(tmp_path):
                         "-DFA_D=64", "-S", "--cuda-device-only", "fa3_fwd_inst.hip", "-o", str(isa)], cwd=csrc, check=True,
                        capture_output=True)
         text = isa.read_text()
-        blocks = re.findall(r"\.name:\s+_Z15fa3_fwd4_kernel\w+\n(?:.*\n){0,12}", text)
-        assert blocks, "fa3_fwd4_kernel is not instantiated in the product build"
+        blocks = re.findall(r"\.name:\s+_Z15fa3_fwd[45]_kernel\w+\n(?:.*\n){0,12}", text)
+        assert len(blocks) >= 3, "fa3_fwd4_kernel (causal) and fa3_fwd5_kernel (causal, full) must be in the product build"
         for blk in blocks:
             assert re.search(r"\.private_segment_fixed_size:\s+0\b", blk), blk
             assert re.search(r"\.vgpr_spill_count:\s+0\b", blk), blk

@@ -61,10 +61,10 @@ badk = 0
 kcases = cases + [(1, 2048, 2048, 4, 4, 96, True, 0, 0), (1, 1024, 1536, 4, 2, 88, False, 0, 0), (2, 1024, 1024, 4, 4, 80, False, 0, 0),
                   (1, 2048, 2048, 4, 4, 80, True, 0, 0)]
 for dtype in (torch.bfloat16, torch.float16):
-  for kimpl in (4, 3):
+  for kimpl in (5, 4, 3):
     _lib.lib.mio_dbg_set(1, kimpl)
     for (B, Sq, Sk, H, Hkv, D, causal, qo, ko) in kcases:
-        if Sq <= 128 or (kimpl == 4 and D > 64):
+        if Sq <= 128 or (kimpl >= 4 and D > 64):
             continue
         torch.manual_seed(Sq + Sk + 1)
         q = (torch.randn(B, Sq, H, D, device=dev) * (3 if Sq >= 4096 else 1)).to(dtype)
@@ -106,10 +106,10 @@ VAR = int(os.environ.get("FA4_VAR", "0"))  # fwd4 variant (mio_dbg_set(0, VAR));
 def sel(impl):
     global KP
     KP = (impl >= 6)
-    _lib.lib.mio_dbg_set(1, 4 if impl in (4, 5, 6) else 3)
+    _lib.lib.mio_dbg_set(1, 5 if impl == 8 else (4 if impl in (4, 5, 6) else 3))
     _lib.lib.mio_dbg_set(0, VAR if impl == 5 else 0)
 for causal in (True, False):
-    impls = (3, 4, 5, 6, 7) if (VAR and causal) else (3, 4, 6, 7)
+    impls = (3, 4, 5, 6, 7, 8) if (VAR and causal) else (3, 4, 6, 7, 8)
     res = {i: [] for i in impls}
     for impl in impls:
         sel(impl); run(200, causal)
@@ -119,7 +119,7 @@ for causal in (True, False):
     fl = (2.0 * B * S * (S + 1) * H * D) if causal else 4.0 * B * S * S * H * D
     for impl in impls:
         t = min(res[impl])
-        print(f"causal={int(causal)} fwd{impl if impl < 5 else ('4/var' + str(VAR) if impl == 5 else ('4/k_prescaled' if impl == 6 else '3/k_prescaled'))}: min {t:.4f} ms  {fl / t / 1e9:.0f} TFLOP/s  frac {fl / t / 1e9 / 2500:.3f}", flush=True)
+        print(f"causal={int(causal)} fwd{impl if impl < 5 else ('4/var' + str(VAR) if impl == 5 else ('4/k_prescaled' if impl == 6 else ('3/k_prescaled' if impl == 7 else '5/k_prescaled (16x16x32)')))}: min {t:.4f} ms  {fl / t / 1e9:.0f} TFLOP/s  frac {fl / t / 1e9 / 2500:.3f}", flush=True)
 if VAR:  # the variant's values (causal bf16 only is instantiated)
     _lib.lib.mio_dbg_set(1, 4); _lib.lib.mio_dbg_set(0, VAR)
     o5, l5 = ops.fa3_fwd(q, k, v, causal=True, return_lse=True)

@@ -31,6 +31,8 @@ def short(name):
             return f"{k}<{dt},{ACT.get(vals[-1], vals[-1])}>"
         if k in ("fa3_fwd_kernel", "fa3_fwd2_kernel"):
             return f"{k}<{dt},D{vals[0]},{'causal' if vals[1] == '1' else 'full'}>"
+        if k == "fa3_fwd5_kernel":  # <T, CAUSAL>
+            return f"{k}<{dt},{'causal' if vals[0] == '1' else 'full'}>"
         if k == "fa3_fwd4_kernel":  # <T, CAUSAL, ABL, KPRE>
             return f"{k}<{dt},{'causal' if vals[0] == '1' else 'full'}{',k_prescaled' if vals[-1] == '1' and len(vals) >= 3 else ''}>"
         if k == "fa3_fwd3_kernel":  # <T, D, CAUSAL, STAMP>; the benchmark's head dim 64 keeps the short name bench.py uses
@@ -39,8 +41,10 @@ def short(name):
         return f"{k}<{dt}>"
     if re.match(r"(?:void )?fa3_fwd3_kernel<bool _Accum, bool, E", name):  # <__bf16, true, false> mis-demangled
         return "fa3_fwd3_kernel<bf16,causal>"
-    if re.match(r"(?:void )?fa3_fwd4_kernel<", name):  # the benchmark launches <__bf16, true, 0, true>
+    if re.match(r"(?:void )?fa3_fwd4_kernel<", name):  # <__bf16, true, 0, true>
         return "fa3_fwd4_kernel<bf16,causal,k_prescaled>"
+    if re.match(r"(?:void )?fa3_fwd5_kernel<", name):  # the benchmark launches <__bf16, true>
+        return "fa3_fwd5_kernel<bf16,causal>"
     m = re.match(r"(?:void )?(\w+_kernel)<bool _Accum, int, E(?:, (\d+))?", name)
     if m:  # rocprofv3 mis-demangles <__bf16, 1, ...>: only the gelu_tanh (ACT = 1) GEMMs of the benchmark show up so
         return f"{m.group(1)}<bf16,gelu_tanh>"
