@@ -19,10 +19,24 @@
 // 7) as in fwd4 (conflict-free ds_read_b128 for this lane -> (row, chunk) map too); V rows of 128 B with the 32-byte block b
 // at b ^ ((row >> 1) & 3) (the 8 rows of a half-wave's transposed read then cover 8 different 32-byte blocks of the 256-byte
 // bank row).
+//
+// Software pipeline (one barrier per KV tile).  No LDS read sits in front of its consumer: the fragments are requested one
+// phase ahead, one per micro-step, so the eight waves' 128 KB of LDS reads per tile spread over the whole iteration instead
+// of bursting behind the barrier (tools/fa5_stamps.py: with the reads at the head of their phase the second-dispatched
+// waves waited 580 cycles for their first K fragment and phase 2 ran at the LDS latency, 60 cycles per MFMA pair).
+//   iteration t:  phase 1: S(t+1) = K(t+1) fragments (registers) . Q^T - ref || P(t) = exp2(S(t)) || request V(t) fragments
+//                 reference test (rare: move), edge masks of S(t+1)
+//                 wait for this wave's share of tile t+2, barrier, DMA of tile t+4
+//                 phase 2: O^T += V(t) fragments . P(t), row sums || request K(t+2) fragments
+// A K fragment dies in the step that a V fragment is born in and vice versa: ~36 fragment registers live.  Tiles t .. t+4
+// are live or in flight: 8 LDS stages of 16 KB.
 #pragma once
 #include "fa3_fwd4_kernel.h"
 
-template <typename T, bool CAUSAL>
+constexpr int FA5_STAGES = 8;
+constexpr int FA5_SMEM = FA5_STAGES * FA4_STAGE;
+
+template <typename T, bool CAUSAL, bool STAMP = false>
 __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
   using X8 = typename DT<T>::x8;
   using X4 = typename DT<T>::x4;
@@ -83,8 +97,14 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
     offvl = rowl * vs2 + 16 * vc;
   }
 
+  // diagnostic build (STAMP): cycles per region summed over both passes, p.mask doubles as the record buffer
+  unsigned long long st_all[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (STAMP) st_all[7] = __builtin_amdgcn_s_memtime();
+
   const int npass = (CAUSAL && (p.nqblk - 1 - qi) != qi) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
+    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
+    if constexpr (STAMP) pt0 = __builtin_amdgcn_s_memtime();
     const int qblk = CAUSAL ? (pass == 0 ? p.nqblk - 1 - qi : qi) : qi;
     const int q0 = qblk * FA4_BM;
     const int wrow0 = q0 + wave * 32;
@@ -131,7 +151,7 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       const char* kb = (const char*)kbase + ko;
       const char* vb = (const char*)vbase + vo;
       const bool lastt = (tile == last_tile);
-      const uint32_t lds = (uint32_t)(size_t)((MIO_LDS char*)(smem + (tile_ & (FA4_STAGES - 1)) * FA4_STAGE)) + 1024 * wave;
+      const uint32_t lds = (uint32_t)(size_t)((MIO_LDS char*)(smem + (tile_ & (FA5_STAGES - 1)) * FA4_STAGE)) + 1024 * wave;
       const int ok_ = lastt ? offkl : offk, ov_ = lastt ? offvl : offv;
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds), "v"(ok_), "s"(kb) : "memory", "m0");
       asm volatile("s_add_i32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
@@ -139,11 +159,6 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
                    : "s"(lds), "n"(FA4_KBYTES), "v"(ov_), "s"(vb)
                    : "memory", "m0", "scc");
     };
-
-    __syncthreads();  // the previous pass is done with every LDS stage
-    stage_dma(0);
-    stage_dma(1);
-    stage_dma(2);
 
     // ---- Q fragments (B operand: lane (c16, g) holds Q[qrow[qg]][32 ds + 8 g .. +7]); rows past Sq / chunks past D are zero
     X8 qf[NQG][NDS];
@@ -159,6 +174,12 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
         qf[qg][ds] = __builtin_bit_cast(X8, raw);
       }
     }
+    asm volatile("s_barrier" ::: "memory");  // the previous pass is done with every LDS stage
+    stage_dma(0);
+    stage_dma(1);
+    stage_dma(2);
+    stage_dma(3);
+
     f32x4_t O[NDT][NQG], L[NQG];
 #pragma unroll
     for (int qg = 0; qg < NQG; ++qg) {
@@ -174,23 +195,24 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
     uint32_t orw = 0u;
     f32x4_t nref4[NQG] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
 
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW) : "memory");  // tiles 0 and 1 have landed, tile 2 may still fly
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * UPW) : "memory");  // tiles 0 and 1 have landed, 2 and 3 may fly
 
     f32x4_t S[2][NKT][NQG];  // score tiles: buffer (t & 1), 16-key tile, query group
     u32x4_t pfw[NS][NQG];    // P^T fragments: 32-key step s, query group
-    X8 vf[2];                // V^T fragments: ring of two
+    X8 kf[NKT * NDS];        // K fragments of the next score tile: index 2 kt + ds
+    X8 vf[NS * NDT];         // V^T fragments of the current tile: index 4 s + dt
 
-    auto read_k = [&](X8 (&kf)[NKT][NDS], const char* kb) {
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int ds = 0; ds < NDS; ++ds) kf[kt][ds] = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + 2048 * kt + k_rd[ds]));
+    auto read_k = [&](const char* kb, auto F_) {  // fragment f = 2 kt + ds
+      constexpr int f = decltype(F_)::value;
+      kf[f] = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + 2048 * (f >> 1) + k_rd[f & 1]));
     };
-    auto qk_one = [&](auto NB_, auto J_, X8 (&kf)[NKT][NDS]) {  // MFMA j of the 16: kt = j / 4, ds = (j / 2) % 2, qg = j % 2
-      constexpr int nb = decltype(NB_)::value, j = decltype(J_)::value, kt = j >> 2, ds = (j >> 1) & 1, qg = j & 1;
-      if constexpr (ds == 0) S[nb][kt][qg] = DT<T>::mfma16(kf[kt][0], qf[qg][0], nref4[qg]);
-      else S[nb][kt][qg] = DT<T>::mfma16(kf[kt][1], qf[qg][1], S[nb][kt][qg]);
+    auto qk_pair = [&](auto NB_, auto F_) {  // the two MFMAs (query groups 0, 1) of K fragment f = 2 kt + ds
+      constexpr int nb = decltype(NB_)::value, f = decltype(F_)::value, kt = f >> 1, ds = f & 1;
+#pragma unroll
+      for (int qg = 0; qg < NQG; ++qg) {
+        if constexpr (ds == 0) S[nb][kt][qg] = DT<T>::mfma16(kf[f], qf[qg][0], nref4[qg]);
+        else S[nb][kt][qg] = DT<T>::mfma16(kf[f], qf[qg][1], S[nb][kt][qg]);
+      }
     };
     // one exp / convert unit: the 4 scores of (key tile kt, query group qg) -> two words of P^T fragment (kt / 2, qg)
     auto exp_unit = [&](auto CB_, auto U_) {
@@ -205,51 +227,47 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       pfw[kt >> 1][qg][2 * (kt & 1) + 0] = w0;
       pfw[kt >> 1][qg][2 * (kt & 1) + 1] = w1;
     };
-    auto read_v = [&](const char* vb, auto F_) {  // fragment f = 4 s + dt into vf[f & 1]
+    auto read_v = [&](const char* vb, auto F_) {  // fragment f = 4 s + dt
       constexpr int f = decltype(F_)::value, s = f >> 2, dt = f & 3;
       const X4 lo = DT<T>::ds_read_tr(vb + 4096 * s + v_rd[dt]);
       const X4 hi = DT<T>::ds_read_tr(vb + 4096 * s + 2048 + v_rd[dt]);
       X8 x;
       x[0] = lo[0]; x[1] = lo[1]; x[2] = lo[2]; x[3] = lo[3];
       x[4] = hi[0]; x[5] = hi[1]; x[6] = hi[2]; x[7] = hi[3];
-      vf[f & 1] = x;
+      vf[f] = x;
     };
-    // ---- phase 1: S[cb ^ 1] = scores of the next tile (K image at kb) minus the reference (C operand)  ||  P = exp2(S[cb]).
-    // All eight K fragments are requested first, one exp unit runs under their latency, then two MFMAs + one unit per step.
-    auto phase1 = [&](auto CB_, auto DO_EXP_, const char* kb, const char* vb) {
+    // ---- phase 1: S[cb ^ 1] = scores of the next tile (its K fragments are in kf) minus the reference (C operand)  ||
+    // P = exp2(S[cb])  ||  the V fragments of the current tile (image at vb) are requested.  One exp unit, then two MFMAs +
+    // one unit + one fragment request per step.
+    auto phase1 = [&](auto CB_, auto DO_EXP_, const char* vb) {
       constexpr int cb = decltype(CB_)::value, nb = cb ^ 1;
       constexpr bool DO_EXP = decltype(DO_EXP_)::value != 0;
-      X8 kf[NKT][NDS];
-      read_k(kf, kb);
-      __builtin_amdgcn_sched_barrier(0);
       if constexpr (DO_EXP) {
         exp_unit(CB_, IC(0));
         __builtin_amdgcn_sched_barrier(0);
       }
       fa2_for<8>([&](auto ST_) {
         constexpr int st = decltype(ST_)::value;
-        qk_one(IC(nb), IC(2 * st), kf);
-        qk_one(IC(nb), IC(2 * st + 1), kf);
+        qk_pair(IC(nb), ST_);
         if constexpr (DO_EXP && st < 7) exp_unit(CB_, IC(st + 1));
-        if constexpr (DO_EXP && st == 5) read_v(vb, IC(0));  // the first V fragment of phase 2, early
+        if constexpr (DO_EXP) read_v(vb, ST_);
         __builtin_amdgcn_sched_barrier(0);
       });
     };
-    // ---- phase 2: O^T += V^T . P^T, L += ones . P^T (V image at vb): 10 steps of two MFMAs (8 V fragments x 2 query groups,
-    // the row sums behind each 32-key step); the next V fragment is requested one step ahead
-    auto phase2 = [&](const char* vb) {
-      fa2_for<NS>([&](auto S_) {
-        constexpr int s = decltype(S_)::value;
-        fa2_for<NDT>([&](auto DT_I) {
-          constexpr int dt = decltype(DT_I)::value, f = 4 * s + dt;
-          O[dt][0] = DT<T>::mfma16(vf[f & 1], __builtin_bit_cast(X8, pfw[s][0]), O[dt][0]);
-          O[dt][1] = DT<T>::mfma16(vf[f & 1], __builtin_bit_cast(X8, pfw[s][1]), O[dt][1]);
-          if constexpr (f + 1 < 8) read_v(vb, IC(f + 1));
-          __builtin_amdgcn_sched_barrier(0);
-        });
-        L[0] = DT<T>::mfma16(ones, __builtin_bit_cast(X8, pfw[s][0]), L[0]);
-        L[1] = DT<T>::mfma16(ones, __builtin_bit_cast(X8, pfw[s][1]), L[1]);
+    // ---- phase 2: O^T += V^T . P^T, L += ones . P^T: 10 steps of two MFMAs (8 V fragments x 2 query groups, the row sums
+    // behind each 32-key step)  ||  the K fragments of the tile after the next (image at kb) are requested
+    auto phase2 = [&](const char* kb) {
+      fa2_for<NS * NDT>([&](auto F_) {
+        constexpr int f = decltype(F_)::value, s = f >> 2, dt = f & 3;
+        O[dt][0] = DT<T>::mfma16(vf[f], __builtin_bit_cast(X8, pfw[s][0]), O[dt][0]);
+        O[dt][1] = DT<T>::mfma16(vf[f], __builtin_bit_cast(X8, pfw[s][1]), O[dt][1]);
+        read_k(kb, F_);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (dt == NDT - 1) {
+          L[0] = DT<T>::mfma16(ones, __builtin_bit_cast(X8, pfw[s][0]), L[0]);
+          L[1] = DT<T>::mfma16(ones, __builtin_bit_cast(X8, pfw[s][1]), L[1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       });
     };
     // masks of an edge tile on S[nb]; first key kv0n.  Key kv0n + 16 kt + 4 g + i is visible to query group qg's row iff <= klim
@@ -306,30 +324,43 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       fresh_any = __builtin_amdgcn_ballot_w64(fresh[0] || fresh[1]) != 0;
     };
     auto is_edge = [&](int t) -> bool { return t >= first_edge; };
-    auto land = [&]() {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW) : "memory");
-      __syncthreads();
+    auto land = [&]() {  // this wave's share of tile t + 2 has landed (tile t + 3 may still fly); no LDS read is waited for
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(UPW) : "memory");
     };
-    auto stg = [&](int tile) -> const char* { return smem + (tile & (FA4_STAGES - 1)) * FA4_STAGE; };
+    auto stg = [&](int tile) -> const char* { return smem + (tile & (FA5_STAGES - 1)) * FA4_STAGE; };
 
+    if constexpr (STAMP) pt1 = __builtin_amdgcn_s_memtime();
     int t = 0;
-    // ---- scores, masks and reference of tile 0
+    // ---- scores, masks and reference of tile 0; K fragments of tile 1
     if (n_w > 0) {
-      phase1(IC(1), IC(0), stg(0), stg(0));
+      fa2_for<8>([&](auto F_) { read_k(stg(0), F_); });
+      phase1(IC(1), IC(0), stg(0));
       if (is_edge(0)) mask_tile(IC(0), 0);
       move_ref(IC(0), IC(0));
+      fa2_for<8>([&](auto F_) { read_k(stg(1), F_); });
     }
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0};
     auto iter = [&](int t, auto CB_) {
       constexpr int cb = decltype(CB_)::value;
+      unsigned long long c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+      if constexpr (STAMP) c1 = __builtin_amdgcn_s_memtime();
       const bool has_next = (t + 1 < n_w);
       orw = 0u;
-      phase1(CB_, IC(1), stg(t + 1), stg(t));
+      phase1(CB_, IC(1), stg(t));
+      if constexpr (STAMP) c2 = __builtin_amdgcn_s_memtime();
       if (__builtin_amdgcn_ballot_w64((orw & 0x40004000u) != 0u) != 0 || fresh_any) move_ref(CB_, IC(1));
       if (has_next && is_edge(t + 1)) mask_tile(IC(cb ^ 1), (t + 1) * FA_BN);
-      stage_dma(t + 3);
-      phase2(stg(t));
+      if constexpr (STAMP) c3 = __builtin_amdgcn_s_memtime();
       land();
+      stage_dma(t + 4);
+      if constexpr (STAMP) c4 = __builtin_amdgcn_s_memtime();
+      phase2(stg(t + 2));
+      if constexpr (STAMP) {
+        c5 = __builtin_amdgcn_s_memtime();
+        st_sum[0] += c2 - c1; st_sum[1] += c3 - c2; st_sum[2] += c5 - c4; st_sum[3] += c4 - c3;
+      }
     };
+    if constexpr (STAMP) pt2 = __builtin_amdgcn_s_memtime();
     for (; t + 1 < n_w; t += 2) {
       iter(t, IC(0));
       iter(t + 1, IC(1));
@@ -338,11 +369,22 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       iter(t, IC(0));
       ++t;
     }
-    for (; t < n_tiles; ++t) {
-      stage_dma(t + 3);
+    for (; t < n_tiles; ++t) {  // tiles this wave only helps to move
       land();
+      stage_dma(t + 4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (STAMP) {
+      pt3 = __builtin_amdgcn_s_memtime();
+      st_all[8] += pt1 - pt0;   // Q load, first tiles requested and landed
+      st_all[9] += pt2 - pt1;   // tile 0 scores / masks / reference
+      st_all[10] += pt3 - pt2;  // tile loop + helper iterations + drain
+      st_all[11] -= pt3;        // (+ end of epilogue below)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) st_all[i] += st_sum[i];
+      st_all[5] += n_w;
+      st_all[6] += n_tiles;
+    }
 
     // ---- epilogue: lane (c16, g) holds O[query qrow[qg]][d = 16 dt + 4 g + i]: one 8-byte store per (dt, qg)
 #pragma unroll
@@ -361,6 +403,18 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
         if (q_ok[qg] && d0 < p.D) *(u32x2_t*)(op + d0) = w;
       }
     }
+    if constexpr (STAMP) st_all[11] += __builtin_amdgcn_s_memtime();
   }  // pass
+  if constexpr (STAMP) {  // [block][wave][16] u64; [7] = wave lifetime
+    if (lane == 0 && p.mask != nullptr) {
+      unsigned long long* d = (unsigned long long*)p.mask + ((size_t)blockIdx.x * 8 + wave) * 16;
+      const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+#pragma unroll
+      for (int i = 0; i < 7; ++i) d[i] = st_all[i];
+      d[7] = t_end - st_all[7];
+#pragma unroll
+      for (int i = 8; i < 12; ++i) d[i] = st_all[i];
+    }
+  }
 #undef IC
 }

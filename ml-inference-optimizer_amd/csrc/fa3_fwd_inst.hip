@@ -168,11 +168,22 @@ static int launch_five(FaDev p, hipStream_t stream) {
   p.qgrid = CAUSAL ? (p.nqblk + 1) / 2 : p.nqblk;
   const int grid = p.qgrid * p.B * p.H;
   void (*kern)(const FaDev) = fa3_fwd5_kernel<FaT, CAUSAL>;
+#if defined(MIO_DIAG) && FA_TYPE_ID == 0
+  static const char* dbg_ptr = std::getenv("MIO_FA_DBG_PTR");  // in-kernel phase stamps (tools/fa5_stamps.py)
+  if (dbg_ptr != nullptr) {
+    auto kd = fa3_fwd5_kernel<FaT, CAUSAL, true>;
+    p.mask = (const void*)std::strtoull(dbg_ptr, nullptr, 0);
+    hipError_t ed = hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, FA5_SMEM);
+    if (ed != hipSuccess) return mio_fail(std::string("fa3_fwd5 (stamps): hipFuncSetAttribute: ") + hipGetErrorString(ed));
+    hipLaunchKernelGGL(kd, dim3(grid), dim3(512), FA5_SMEM, stream, p);
+    return 0;
+  }
+#endif
   static std::once_flag once;
   static hipError_t ea = hipSuccess;
-  std::call_once(once, [&] { ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, FA4_SMEM); });
+  std::call_once(once, [&] { ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, FA5_SMEM); });
   if (ea != hipSuccess) return mio_fail(std::string("fa3_fwd5: hipFuncSetAttribute: ") + hipGetErrorString(ea));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), FA4_SMEM, stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), FA5_SMEM, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mio_fail(std::string("fa3_fwd5 launch: ") + hipGetErrorString(e));
   return 0;
