@@ -34,9 +34,14 @@
 #include "fa3_fwd4_kernel.h"
 
 constexpr int FA5_STAGES = 8;
+constexpr int FA5_TPB = 2;  // KV tiles per barrier
+// Waves 4..7 (the second wave of each SIMD) meet the barrier BEFORE the QK^T half of an iteration, waves 0..3 behind it: the
+// two waves of a SIMD then run opposite halves (vector-heavy QK^T || exp beside matrix-only PV) instead of queueing for the
+// same unit
+constexpr bool FA5_STAGGER = true;
 constexpr int FA5_SMEM = FA5_STAGES * FA4_STAGE;
 
-template <typename T, bool CAUSAL, bool STAMP = false>
+template <typename T, bool CAUSAL, bool STAMP = false, int ABL = 0>  // ABL: timing-only ablations of the diagnostic build
 __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
   using X8 = typename DT<T>::x8;
   using X4 = typename DT<T>::x4;
@@ -143,8 +148,9 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       lim0 = c0 < lim0 ? c0 : lim0;
     }
     const int first_edge = (lim0 + 1) / FA_BN;
+    const bool late = wave >= 4;
 
-    auto stage_dma = [&](int tile_) {
+    auto stage_dma = [&](int tile_) __attribute__((always_inline)) {
       const int tile = tile_ < n_tiles_dma ? tile_ : n_tiles_dma - 1;
       const uint32_t ko = __builtin_amdgcn_readfirstlane((uint32_t)(tile * FA_BN) * (uint32_t)ks2);
       const uint32_t vo = __builtin_amdgcn_readfirstlane((uint32_t)(tile * FA_BN) * (uint32_t)vs2);
@@ -202,11 +208,11 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
     X8 kf[NKT * NDS];        // K fragments of the next score tile: index 2 kt + ds
     X8 vf[NS * NDT];         // V^T fragments of the current tile: index 4 s + dt
 
-    auto read_k = [&](const char* kb, auto F_) {  // fragment f = 2 kt + ds
+    auto read_k = [&](const char* kb, auto F_) __attribute__((always_inline)) {  // fragment f = 2 kt + ds
       constexpr int f = decltype(F_)::value;
       kf[f] = __builtin_bit_cast(X8, *(const u32x4_t*)(kb + 2048 * (f >> 1) + k_rd[f & 1]));
     };
-    auto qk_pair = [&](auto NB_, auto F_) {  // the two MFMAs (query groups 0, 1) of K fragment f = 2 kt + ds
+    auto qk_pair = [&](auto NB_, auto F_) __attribute__((always_inline)) {  // the two MFMAs (query groups 0, 1) of K fragment f = 2 kt + ds
       constexpr int nb = decltype(NB_)::value, f = decltype(F_)::value, kt = f >> 1, ds = f & 1;
 #pragma unroll
       for (int qg = 0; qg < NQG; ++qg) {
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       }
     };
     // one exp / convert unit: the 4 scores of (key tile kt, query group qg) -> two words of P^T fragment (kt / 2, qg)
-    auto exp_unit = [&](auto CB_, auto U_) {
+    auto exp_unit = [&](auto CB_, auto U_) __attribute__((always_inline)) {
       constexpr int cb = decltype(CB_)::value, u = decltype(U_)::value, kt = u >> 1, qg = u & 1;
       const float e0 = fast_exp2(S[cb][kt][qg][0]);
       const float e1 = fast_exp2(S[cb][kt][qg][1]);
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       pfw[kt >> 1][qg][2 * (kt & 1) + 0] = w0;
       pfw[kt >> 1][qg][2 * (kt & 1) + 1] = w1;
     };
-    auto read_v = [&](const char* vb, auto F_) {  // fragment f = 4 s + dt
+    auto read_v = [&](const char* vb, auto F_) __attribute__((always_inline)) {  // fragment f = 4 s + dt
       constexpr int f = decltype(F_)::value, s = f >> 2, dt = f & 3;
       const X4 lo = DT<T>::ds_read_tr(vb + 4096 * s + v_rd[dt]);
       const X4 hi = DT<T>::ds_read_tr(vb + 4096 * s + 2048 + v_rd[dt]);
@@ -239,14 +245,14 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
     // ---- phase 1: S[cb ^ 1] = scores of the next tile (its K fragments are in kf) minus the reference (C operand)  ||
     // P = exp2(S[cb])  ||  the V fragments of the current tile (image at vb) are requested.  One exp unit, then two MFMAs +
     // one unit + one fragment request per step.
-    auto phase1 = [&](auto CB_, auto DO_EXP_, const char* vb) {
+    auto phase1 = [&](auto CB_, auto DO_EXP_, const char* vb) __attribute__((always_inline)) {
       constexpr int cb = decltype(CB_)::value, nb = cb ^ 1;
       constexpr bool DO_EXP = decltype(DO_EXP_)::value != 0;
       if constexpr (DO_EXP) {
         exp_unit(CB_, IC(0));
         __builtin_amdgcn_sched_barrier(0);
       }
-      fa2_for<8>([&](auto ST_) {
+      fa2_for<8>([&](auto ST_) __attribute__((always_inline)) {
         constexpr int st = decltype(ST_)::value;
         qk_pair(IC(nb), ST_);
         if constexpr (DO_EXP && st < 7) exp_unit(CB_, IC(st + 1));
@@ -256,8 +262,8 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
     };
     // ---- phase 2: O^T += V^T . P^T, L += ones . P^T: 10 steps of two MFMAs (8 V fragments x 2 query groups, the row sums
     // behind each 32-key step)  ||  the K fragments of the tile after the next (image at kb) are requested
-    auto phase2 = [&](const char* kb) {
-      fa2_for<NS * NDT>([&](auto F_) {
+    auto phase2 = [&](const char* kb) __attribute__((always_inline)) {
+      fa2_for<NS * NDT>([&](auto F_) __attribute__((always_inline)) {
         constexpr int f = decltype(F_)::value, s = f >> 2, dt = f & 3;
         O[dt][0] = DT<T>::mfma16(vf[f], __builtin_bit_cast(X8, pfw[s][0]), O[dt][0]);
         O[dt][1] = DT<T>::mfma16(vf[f], __builtin_bit_cast(X8, pfw[s][1]), O[dt][1]);
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       });
     };
     // masks of an edge tile on S[nb]; first key kv0n.  Key kv0n + 16 kt + 4 g + i is visible to query group qg's row iff <= klim
-    auto mask_tile = [&](auto NB_, int kv0n) {
+    auto mask_tile = [&](auto NB_, int kv0n) __attribute__((always_inline)) {
       constexpr int nb = decltype(NB_)::value;
 #pragma unroll
       for (int qg = 0; qg < NQG; ++qg) {
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
     };
     // move the reference of rows that need it for the tile whose scores sit in S[cb] at the OLD reference (fa3_fwd4 KPRE).
     // WHEN = 0: tile 0 of a pass; 1: after phase 1 -- also shift S[cb ^ 1] and recompute the tile's P.  Rare.
-    auto move_ref = [&](auto CB_, auto WHEN_) {
+    auto move_ref = [&](auto CB_, auto WHEN_) __attribute__((always_inline)) {
       constexpr int cb = decltype(CB_)::value;
       constexpr int WHEN = decltype(WHEN_)::value;
 #pragma unroll
@@ -319,40 +325,67 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       }
       if constexpr (WHEN == 1) {
         orw = 0u;
-        fa2_for<8>([&](auto U_) { exp_unit(CB_, U_); });
+        fa2_for<8>([&](auto U_) __attribute__((always_inline)) { exp_unit(CB_, U_); });
       }
       fresh_any = __builtin_amdgcn_ballot_w64(fresh[0] || fresh[1]) != 0;
     };
-    auto is_edge = [&](int t) -> bool { return t >= first_edge; };
-    auto land = [&]() {  // this wave's share of tile t + 2 has landed (tile t + 3 may still fly); no LDS read is waited for
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(UPW) : "memory");
+    auto is_edge = [&](int t) __attribute__((always_inline)) -> bool { return t >= first_edge; };
+    auto land = [&]() __attribute__((always_inline)) {  // this wave's share of tile t + 2 has landed (tile t + 3 may still fly); no LDS read is waited for
+      constexpr int N = FA5_TPB == 1 ? UPW : 0;
+      if constexpr (ABL & 4) asm volatile("s_barrier" ::: "memory");
+      else if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
     };
-    auto stg = [&](int tile) -> const char* { return smem + (tile & (FA5_STAGES - 1)) * FA4_STAGE; };
+    // end of the QK^T half of iteration t: every FA5_TPB-th iteration waits for its DMA shares, meets the other waves and
+    // requests the next FA5_TPB tiles (tiles up to t + 3 have landed behind that barrier)
+    auto sync_and_dma = [&](int t, auto EVEN_) __attribute__((always_inline)) {  // EVEN_: 1 / 0 = t is even / odd, 2 = look
+      constexpr int EVEN = decltype(EVEN_)::value;
+      if constexpr (FA5_TPB == 1) {
+        land();
+        if constexpr (!(ABL & 8)) stage_dma(t + 4);
+      } else if constexpr (EVEN != 0) {
+        if (EVEN == 1 || !(t & 1)) {
+          land();
+          if constexpr (!(ABL & 8)) {
+            stage_dma(t + 4);
+            stage_dma(t + 5);
+          }
+        }
+      }
+    };
+    auto stg = [&](int tile) __attribute__((always_inline)) -> const char* { return smem + (tile & (FA5_STAGES - 1)) * FA4_STAGE; };
 
     if constexpr (STAMP) pt1 = __builtin_amdgcn_s_memtime();
     int t = 0;
     // ---- scores, masks and reference of tile 0; K fragments of tile 1
     if (n_w > 0) {
-      fa2_for<8>([&](auto F_) { read_k(stg(0), F_); });
+      fa2_for<8>([&](auto F_) __attribute__((always_inline)) { read_k(stg(0), F_); });
       phase1(IC(1), IC(0), stg(0));
       if (is_edge(0)) mask_tile(IC(0), 0);
       move_ref(IC(0), IC(0));
-      fa2_for<8>([&](auto F_) { read_k(stg(1), F_); });
+      fa2_for<8>([&](auto F_) __attribute__((always_inline)) { read_k(stg(1), F_); });
     }
     unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0};
-    auto iter = [&](int t, auto CB_) {
+    auto iter = [&](int t, auto CB_) __attribute__((always_inline)) {
       constexpr int cb = decltype(CB_)::value;
       unsigned long long c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
       if constexpr (STAMP) c1 = __builtin_amdgcn_s_memtime();
       const bool has_next = (t + 1 < n_w);
+      if constexpr (FA5_STAGGER) {
+        if (late) sync_and_dma(t, IC(cb ^ 1));
+      }
       orw = 0u;
       phase1(CB_, IC(1), stg(t));
       if constexpr (STAMP) c2 = __builtin_amdgcn_s_memtime();
-      if (__builtin_amdgcn_ballot_w64((orw & 0x40004000u) != 0u) != 0 || fresh_any) move_ref(CB_, IC(1));
+      if constexpr (ABL & 1) asm volatile("" ::"v"(orw));
+      else if (__builtin_amdgcn_ballot_w64((orw & 0x40004000u) != 0u) != 0 || fresh_any) move_ref(CB_, IC(1));
       if (has_next && is_edge(t + 1)) mask_tile(IC(cb ^ 1), (t + 1) * FA_BN);
       if constexpr (STAMP) c3 = __builtin_amdgcn_s_memtime();
-      land();
-      stage_dma(t + 4);
+      if constexpr (FA5_STAGGER) {
+        if (!late) sync_and_dma(t, IC(cb ^ 1));
+      } else {
+        sync_and_dma(t, IC(cb ^ 1));
+      }
       if constexpr (STAMP) c4 = __builtin_amdgcn_s_memtime();
       phase2(stg(t + 2));
       if constexpr (STAMP) {
@@ -369,10 +402,7 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       iter(t, IC(0));
       ++t;
     }
-    for (; t < n_tiles; ++t) {  // tiles this wave only helps to move
-      land();
-      stage_dma(t + 4);
-    }
+    for (; t < n_tiles; ++t) sync_and_dma(t, IC(2));  // tiles this wave only helps to move
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (STAMP) {
       pt3 = __builtin_amdgcn_s_memtime();

@@ -178,6 +178,23 @@ static int launch_five(FaDev p, hipStream_t stream) {
     hipLaunchKernelGGL(kd, dim3(grid), dim3(512), FA5_SMEM, stream, p);
     return 0;
   }
+  if constexpr (CAUSAL) {  // timing-only ablations (tools/fa5_ablate.py): mio_dbg_set(0, bits)
+    void (*ka)(const FaDev) = nullptr;
+    switch (mio_dbg_get(0)) {
+      case 1: ka = fa3_fwd5_kernel<FaT, CAUSAL, false, 1>; break;
+      case 2: ka = fa3_fwd5_kernel<FaT, CAUSAL, false, 2>; break;
+      case 4: ka = fa3_fwd5_kernel<FaT, CAUSAL, false, 4>; break;
+      case 8: ka = fa3_fwd5_kernel<FaT, CAUSAL, false, 8>; break;
+      case 15: ka = fa3_fwd5_kernel<FaT, CAUSAL, false, 15>; break;
+      default: break;
+    }
+    if (ka != nullptr) {
+      hipError_t ed = hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, FA5_SMEM);
+      if (ed != hipSuccess) return mio_fail(std::string("fa3_fwd5 (ablation): hipFuncSetAttribute: ") + hipGetErrorString(ed));
+      hipLaunchKernelGGL(ka, dim3(grid), dim3(512), FA5_SMEM, stream, p);
+      return 0;
+    }
+  }
 #endif
   static std::once_flag once;
   static hipError_t ea = hipSuccess;
