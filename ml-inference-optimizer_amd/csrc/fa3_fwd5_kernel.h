@@ -34,7 +34,6 @@
 #include "fa3_fwd4_kernel.h"
 
 constexpr int FA5_STAGES = 8;
-constexpr int FA5_TPB = 2;  // KV tiles per barrier
 // Waves 4..7 (the second wave of each SIMD) meet the barrier BEFORE the QK^T half of an iteration, waves 0..3 behind it: the
 // two waves of a SIMD then run opposite halves (vector-heavy QK^T || exp beside matrix-only PV) instead of queueing for the
 // same unit
@@ -107,11 +106,44 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
   if constexpr (STAMP) st_all[7] = __builtin_amdgcn_s_memtime();
 
   const int npass = (CAUSAL && (p.nqblk - 1 - qi) != qi) ? 2 : 1;
+  auto pass_q0 = [&](int pass) __attribute__((always_inline)) -> int {
+    return (CAUSAL ? (pass == 0 ? p.nqblk - 1 - qi : qi) : qi) * FA4_BM;
+  };
+  auto pass_tiles = [&](int pass) __attribute__((always_inline)) -> int {  // KV tiles the workgroup walks in that pass
+    if (!CAUSAL) return (p.Sk + FA_BN - 1) / FA_BN;
+    int kmax = pass_q0(pass) + FA4_BM - 1 + p.q_offset - p.k_offset;
+    if (kmax > p.Sk - 1) kmax = p.Sk - 1;
+    return kmax < 0 ? 0 : kmax / FA_BN + 1;
+  };
+  // Q fragments (B operand: lane (c16, g) holds Q[row][32 ds + 8 g .. +7]); rows past Sq / chunks past D are zero
+  auto load_q = [&](int pass, X8 (&dst)[NQG][NDS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qg = 0; qg < NQG; ++qg) {
+      const int row = pass_q0(pass) + wave * 32 + 16 * qg + c16;
+      const bool ok = row < p.Sq;
+      const T* qp = (const T*)p.q + b * p.qs_b + head * p.qs_h + (int64_t)(ok ? row : 0) * p.qs_s;
+#pragma unroll
+      for (int ds = 0; ds < NDS; ++ds) {
+        const int d0 = 32 * ds + 8 * g;
+        u32x4_t raw = *(const u32x4_t*)(qp + (d0 < p.D ? d0 : 0));
+        const uint32_t keep = (ok && d0 < p.D) ? 0xffffffffu : 0u;
+        raw[0] &= keep; raw[1] &= keep; raw[2] &= keep; raw[3] &= keep;
+        dst[qg][ds] = __builtin_bit_cast(X8, raw);
+      }
+    }
+  };
+  // The KV tiles of both passes (same head, so the same K / V rows) form ONE stream of "virtual" tiles: tbase = virtual index
+  // of the current pass' tile 0, vnext = next virtual tile to request, vseen = every virtual tile below it has landed and is
+  // visible to all waves.  Tile v lives in LDS stage v % FA5_STAGES.  The first tiles of the second pass are requested by the
+  // last iterations of the first, and its Q rows in front of the first pass' epilogue.
+  int tbase = 0, vnext = 0, vseen = 0;
+  X8 qf_next[NQG][NDS];
+  load_q(0, qf_next);
+
   for (int pass = 0; pass < npass; ++pass) {
     unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
     if constexpr (STAMP) pt0 = __builtin_amdgcn_s_memtime();
-    const int qblk = CAUSAL ? (pass == 0 ? p.nqblk - 1 - qi : qi) : qi;
-    const int q0 = qblk * FA4_BM;
+    const int q0 = pass_q0(pass);
     const int wrow0 = q0 + wave * 32;
     int qrow[NQG];
     bool q_ok[NQG];
@@ -121,19 +153,14 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       q_ok[qg] = qrow[qg] < p.Sq;
     }
 
-    int n_tiles, n_w;
+    const int n_tiles = pass_tiles(pass);
+    const int n_tiles_next = pass + 1 < npass ? pass_tiles(pass + 1) : 0;
+    int n_w = n_tiles;
     if (CAUSAL) {
-      int kmax = q0 + FA4_BM - 1 + p.q_offset - p.k_offset;
-      if (kmax > p.Sk - 1) kmax = p.Sk - 1;
-      n_tiles = kmax < 0 ? 0 : kmax / FA_BN + 1;
       int kw = wrow0 + 31 + p.q_offset - p.k_offset;
       if (kw > p.Sk - 1) kw = p.Sk - 1;
       n_w = kw < 0 ? 0 : kw / FA_BN + 1;
-    } else {
-      n_tiles = (p.Sk + FA_BN - 1) / FA_BN;
-      n_w = n_tiles;
     }
-    const int n_tiles_dma = n_tiles > 0 ? n_tiles : 1;
     int klim[NQG], lim0 = p.Sk - 1;
 #pragma unroll
     for (int qg = 0; qg < NQG; ++qg) {
@@ -150,8 +177,10 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
     const int first_edge = (lim0 + 1) / FA_BN;
     const bool late = wave >= 4;
 
-    auto stage_dma = [&](int tile_) __attribute__((always_inline)) {
-      const int tile = tile_ < n_tiles_dma ? tile_ : n_tiles_dma - 1;
+    auto stage_dma = [&](int tile_) __attribute__((always_inline)) {  // tile_: virtual index
+      int tile = tile_ - tbase;
+      if (tile >= n_tiles) tile = (tile - n_tiles < n_tiles_next) ? tile - n_tiles : -1;  // the next pass' tile, or none
+      if (tile < 0) return;
       const uint32_t ko = __builtin_amdgcn_readfirstlane((uint32_t)(tile * FA_BN) * (uint32_t)ks2);
       const uint32_t vo = __builtin_amdgcn_readfirstlane((uint32_t)(tile * FA_BN) * (uint32_t)vs2);
       const char* kb = (const char*)kbase + ko;
@@ -166,25 +195,20 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
                    : "memory", "m0", "scc");
     };
 
-    // ---- Q fragments (B operand: lane (c16, g) holds Q[qrow[qg]][32 ds + 8 g .. +7]); rows past Sq / chunks past D are zero
     X8 qf[NQG][NDS];
 #pragma unroll
-    for (int qg = 0; qg < NQG; ++qg) {
-      const T* qp = (const T*)p.q + b * p.qs_b + head * p.qs_h + (int64_t)(q_ok[qg] ? qrow[qg] : 0) * p.qs_s;
+    for (int qg = 0; qg < NQG; ++qg)
 #pragma unroll
-      for (int ds = 0; ds < NDS; ++ds) {
-        const int d0 = 32 * ds + 8 * g;
-        u32x4_t raw = *(const u32x4_t*)(qp + (d0 < p.D ? d0 : 0));
-        const uint32_t keep = (q_ok[qg] && d0 < p.D) ? 0xffffffffu : 0u;
-        raw[0] &= keep; raw[1] &= keep; raw[2] &= keep; raw[3] &= keep;
-        qf[qg][ds] = __builtin_bit_cast(X8, raw);
-      }
+      for (int ds = 0; ds < NDS; ++ds) qf[qg][ds] = qf_next[qg][ds];
+    // tiles 0 .. 3 of this pass are requested (normally by the previous pass) and tiles 0, 1 have landed
+    while (vnext < tbase + 4) {
+      stage_dma(vnext);
+      ++vnext;
     }
-    asm volatile("s_barrier" ::: "memory");  // the previous pass is done with every LDS stage
-    stage_dma(0);
-    stage_dma(1);
-    stage_dma(2);
-    stage_dma(3);
+    if (vseen < tbase + 2) {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      vseen = vnext;
+    }
 
     f32x4_t O[NDT][NQG], L[NQG];
 #pragma unroll
@@ -200,8 +224,6 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
     bool fresh_any = true;
     uint32_t orw = 0u;
     f32x4_t nref4[NQG] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
-
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * UPW) : "memory");  // tiles 0 and 1 have landed, 2 and 3 may fly
 
     f32x4_t S[2][NKT][NQG];  // score tiles: buffer (t & 1), 16-key tile, query group
     u32x4_t pfw[NS][NQG];    // P^T fragments: 32-key step s, query group
@@ -330,30 +352,25 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       fresh_any = __builtin_amdgcn_ballot_w64(fresh[0] || fresh[1]) != 0;
     };
     auto is_edge = [&](int t) __attribute__((always_inline)) -> bool { return t >= first_edge; };
-    auto land = [&]() __attribute__((always_inline)) {  // this wave's share of tile t + 2 has landed (tile t + 3 may still fly); no LDS read is waited for
-      constexpr int N = FA5_TPB == 1 ? UPW : 0;
-      if constexpr (ABL & 4) asm volatile("s_barrier" ::: "memory");
-      else if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-    };
-    // end of the QK^T half of iteration t: every FA5_TPB-th iteration waits for its DMA shares, meets the other waves and
-    // requests the next FA5_TPB tiles (tiles up to t + 3 have landed behind that barrier)
+    // every second iteration (t even) a wave waits for its DMA shares, meets the other waves (every virtual tile requested
+    // so far is then visible: pass-local tiles up to t + 3) and requests the next two tiles
     auto sync_and_dma = [&](int t, auto EVEN_) __attribute__((always_inline)) {  // EVEN_: 1 / 0 = t is even / odd, 2 = look
       constexpr int EVEN = decltype(EVEN_)::value;
-      if constexpr (FA5_TPB == 1) {
-        land();
-        if constexpr (!(ABL & 8)) stage_dma(t + 4);
-      } else if constexpr (EVEN != 0) {
+      if constexpr (EVEN != 0) {
         if (EVEN == 1 || !(t & 1)) {
-          land();
+          if constexpr (ABL & 4) asm volatile("s_barrier" ::: "memory");
+          else if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+          vseen = vnext;
           if constexpr (!(ABL & 8)) {
-            stage_dma(t + 4);
-            stage_dma(t + 5);
+            stage_dma(vnext);
+            stage_dma(vnext + 1);
           }
+          vnext += 2;
         }
       }
     };
-    auto stg = [&](int tile) __attribute__((always_inline)) -> const char* { return smem + (tile & (FA5_STAGES - 1)) * FA4_STAGE; };
+    auto stg = [&](int tile) __attribute__((always_inline)) -> const char* { return smem + ((tbase + tile) & (FA5_STAGES - 1)) * FA4_STAGE; };
 
     if constexpr (STAMP) pt1 = __builtin_amdgcn_s_memtime();
     int t = 0;
@@ -378,8 +395,8 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       phase1(CB_, IC(1), stg(t));
       if constexpr (STAMP) c2 = __builtin_amdgcn_s_memtime();
       if constexpr (ABL & 1) asm volatile("" ::"v"(orw));
-      else if (__builtin_amdgcn_ballot_w64((orw & 0x40004000u) != 0u) != 0 || fresh_any) move_ref(CB_, IC(1));
-      if (has_next && is_edge(t + 1)) mask_tile(IC(cb ^ 1), (t + 1) * FA_BN);
+      else if (__builtin_expect(__builtin_amdgcn_ballot_w64((orw & 0x40004000u) != 0u) != 0 || fresh_any, 0)) move_ref(CB_, IC(1));
+      if (__builtin_expect(has_next && is_edge(t + 1), 0)) mask_tile(IC(cb ^ 1), (t + 1) * FA_BN);
       if constexpr (STAMP) c3 = __builtin_amdgcn_s_memtime();
       if constexpr (FA5_STAGGER) {
         if (!late) sync_and_dma(t, IC(cb ^ 1));
@@ -403,7 +420,8 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       ++t;
     }
     for (; t < n_tiles; ++t) sync_and_dma(t, IC(2));  // tiles this wave only helps to move
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tbase += n_tiles;
+    if (pass + 1 < npass) load_q(pass + 1, qf_next);  // in front of the epilogue's stores
     if constexpr (STAMP) {
       pt3 = __builtin_amdgcn_s_memtime();
       st_all[8] += pt1 - pt0;   // Q load, first tiles requested and landed
@@ -435,6 +453,7 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
     }
     if constexpr (STAMP) st_all[11] += __builtin_amdgcn_s_memtime();
   }  // pass
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be writing LDS when the wave ends
   if constexpr (STAMP) {  // [block][wave][16] u64; [7] = wave lifetime
     if (lane == 0 && p.mask != nullptr) {
       unsigned long long* d = (unsigned long long*)p.mask + ((size_t)blockIdx.x * 8 + wave) * 16;
