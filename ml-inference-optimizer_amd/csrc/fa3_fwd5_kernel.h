@@ -136,6 +136,13 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
   // of the current pass' tile 0, vnext = next virtual tile to request, vseen = every virtual tile below it has landed and is
   // visible to all waves.  Tile v lives in LDS stage v % FA5_STAGES.  The first tiles of the second pass are requested by the
   // last iterations of the first, and its Q rows in front of the first pass' epilogue.
+  // static priority for the half of the waves that leads (waves 0..3 run half an iteration ahead): -1 % measured; the other
+  // half at priority 1 instead: +3 %.  (Diagnostic library: bits 4 / 5 of xcd_remap = none / the other half.)
+  if (p.xcd_remap & 32) {
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  } else if (!(p.xcd_remap & 16)) {
+    if (wave < 4) __builtin_amdgcn_s_setprio(1);
+  }
   int tbase = 0, vnext = 0, vseen = 0;
   X8 qf_next[NQG][NDS];
   load_q(0, qf_next);

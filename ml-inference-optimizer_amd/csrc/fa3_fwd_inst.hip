@@ -169,6 +169,7 @@ static int launch_five(FaDev p, hipStream_t stream) {
   const int grid = p.qgrid * p.B * p.H;
   void (*kern)(const FaDev) = fa3_fwd5_kernel<FaT, CAUSAL>;
 #if defined(MIO_DIAG) && FA_TYPE_ID == 0
+  p.xcd_remap |= (mio_dbg_get(3) & 3) << 4;  // wave-priority probe (tools/fa5_ablate.py)
   static const char* dbg_ptr = std::getenv("MIO_FA_DBG_PTR");  // in-kernel phase stamps (tools/fa5_stamps.py)
   if (dbg_ptr != nullptr) {
     auto kd = fa3_fwd5_kernel<FaT, CAUSAL, true>;

@@ -26,3 +26,8 @@ for rep in range(2):
         _lib.lib.mio_dbg_set(0, bits)
         print(f"{nm:22s} random {run(*rnd):.4f} ms   zeros {run(*zero):.4f} ms", flush=True)
 _lib.lib.mio_dbg_set(0, 0)
+for rep in range(2):
+    for pr, nm in ((1, "no priorities"), (2, "waves 4-7 at priority 1"), (0, "waves 0-3 at priority 1")):
+        _lib.lib.mio_dbg_set(3, pr)
+        print(f"{nm:26s} random {run(*rnd):.4f} ms   zeros {run(*zero):.4f} ms", flush=True)
+_lib.lib.mio_dbg_set(3, 0)
