@@ -130,10 +130,14 @@ def test_fa3_benchmark_length(dtype, causal, D, S, H):
     (1, 256, 192, 6, 2, 64, True, 64, 128),   # partial overlap: rows that see no key stay "fresh" for the whole pass
     (1, 130, 300, 6, 2, 64, True, 170, 0), (1, 192, 192, 3, 3, 32, True, 0, 0), (1, 2048, 2048, 8, 8, 64, True, 0, 0),
     (1, 2048, 2048, 4, 4, 64, False, 0, 0),
+    (1, 832, 832, 4, 4, 64, True, 0, 0),     # 13 KV tiles in the heavy pass (odd), 4 in the light one: the DMA stream crosses
+    (1, 576, 576, 4, 2, 64, True, 0, 0),     # three 256-row blocks: one causal pair + the single-pass middle block
+    (1, 700, 1100, 4, 4, 64, True, 400, 0),  # Sk > Sq behind an offset: every row sees > 400 keys, ragged last tile
+    (1, 600, 1000, 4, 4, 48, False, 0, 0),
 ])
 def test_fa3_k_prescaled(dtype, B, Sq, Sk, H, Hkv, D, causal, q_off, k_off):
-    """k_prescaled launches (fa3_fwd4_kernel KPRE: reference through the MFMA's C operand, post-exp rescale test on
-    bit 14 of the packed P words): K~ = round16(K * softmax_scale * log2 e) computed in fp32 -- what the projection's
+    """k_prescaled launches (fa3_fwd5_kernel at D <= 64, fa3_fwd3_kernel KPRE above: reference through the MFMA's C
+    operand, post-exp rescale test on bit 14 of the packed P words): K~ = round16(K * softmax_scale * log2 e) computed in fp32 -- what the projection's
     col_scale epilogue hands over -- against the oracle evaluated on (q, K~, v) with scores q . K~ * ln 2.  q is scaled
     up at the long sequence so that rows outgrow their reference by more than 2^(margin + 1) several times (the rare
     branch that recomputes a tile's P)."""
