@@ -347,9 +347,11 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           nref4[qg][i] = -ref[qg];
-          L[qg][i] *= alpha;
+          if constexpr (WHEN != 0) {  // (tile 0: every row is fresh, O and L are still zero)
+            L[qg][i] *= alpha;
 #pragma unroll
-          for (int dt = 0; dt < NDT; ++dt) O[dt][qg][i] *= alpha;
+            for (int dt = 0; dt < NDT; ++dt) O[dt][qg][i] *= alpha;
+          }
         }
       }
       if constexpr (WHEN == 1) {
@@ -385,9 +387,9 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
     if (n_w > 0) {
       fa2_for<8>([&](auto F_) __attribute__((always_inline)) { read_k(stg(0), F_); });
       phase1(IC(1), IC(0), stg(0));
+      fa2_for<8>([&](auto F_) __attribute__((always_inline)) { read_k(stg(1), F_); });  // (land under the reference set-up)
       if (is_edge(0)) mask_tile(IC(0), 0);
       move_ref(IC(0), IC(0));
-      fa2_for<8>([&](auto F_) __attribute__((always_inline)) { read_k(stg(1), F_); });
     }
     unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0};
     auto iter = [&](int t, auto CB_) __attribute__((always_inline)) {
