@@ -20,16 +20,17 @@
 // at b ^ ((row >> 1) & 3) (the 8 rows of a half-wave's transposed read then cover 8 different 32-byte blocks of the 256-byte
 // bank row).
 //
-// Software pipeline (one barrier per KV tile).  No LDS read sits in front of its consumer: the fragments are requested one
-// phase ahead, one per micro-step, so the eight waves' 128 KB of LDS reads per tile spread over the whole iteration instead
-// of bursting behind the barrier (tools/fa5_stamps.py: with the reads at the head of their phase the second-dispatched
-// waves waited 580 cycles for their first K fragment and phase 2 ran at the LDS latency, 60 cycles per MFMA pair).
-//   iteration t:  phase 1: S(t+1) = K(t+1) fragments (registers) . Q^T - ref || P(t) = exp2(S(t)) || request V(t) fragments
+// Software pipeline.  No LDS read sits in front of its consumer: the fragments are requested one half-iteration ahead, one
+// per micro-step, so the eight waves' 128 KB of LDS reads per tile spread over the whole iteration instead of bursting behind
+// the barrier (tools/fa5_stamps.py: with the reads at the head of their phase the second-dispatched waves waited 580 cycles
+// for their first K fragment and the PV half ran at the LDS latency, 60 cycles per MFMA pair).
+//   iteration t:  half 1: S(t+1) = K(t+1) fragments (registers) . Q^T - ref || P(t) = exp2(S(t)) || request V(t) fragments
 //                 reference test (rare: move), edge masks of S(t+1)
-//                 wait for this wave's share of tile t+2, barrier, DMA of tile t+4
-//                 phase 2: O^T += V(t) fragments . P(t), row sums || request K(t+2) fragments
-// A K fragment dies in the step that a V fragment is born in and vice versa: ~36 fragment registers live.  Tiles t .. t+4
-// are live or in flight: 8 LDS stages of 16 KB.
+//                 t even: wait for this wave's DMA shares, barrier (tiles <= t+3 visible), DMA of the next two tiles
+//                 half 2: O^T += V(t) fragments . P(t), row sums || request K(t+2) fragments
+// A K fragment dies in the step that a V fragment is born in and vice versa: ~36 fragment registers live.  Tiles t .. t+5
+// are live or in flight: 8 LDS stages of 16 KB, ONE barrier per two tiles.  The KV tiles of both causal passes (same head)
+// are one stream of "virtual" tiles: the heavy pass' last iterations request the light pass' first tiles.
 #pragma once
 #include "fa3_fwd4_kernel.h"
 
