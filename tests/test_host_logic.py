@@ -373,3 +373,113 @@ def test_gemm_accumulator_file_untouched_by_compiler(tmp_path):
         erf = "DF16bLi2E" in text[a]  # exact-erf GELU: erff() in the read-out spills a few registers (slow, still correct)
         if production and not erf:
             assert not any("scratch_" in l for l in text[a:b + 1]), "register spills in " + text[a]
+
+
+@pytest.mark.parametrize("n1,n2", [(64, 4), (13, 4), (4, 4), (5, 1), (1, 0), (3, 0), (12, 8), (2, 1), (7, 3), (0, 0)])
+def test_fwd5_tile_stream_schedule(n1, n2):
+    """Host-side model of fa3_fwd5_kernel's LDS schedule (csrc/fa3_fwd5_kernel.h): the KV tiles of the one or two causal passes
+    of a workgroup are one stream of virtual tiles in 8 LDS stages; a wave meets the barrier once per two iterations (waves 0-3
+    behind the QK^T half of an even iteration, waves 4-7 in front of it) and requests the next two tiles there.  Checked for
+    every wave, whatever its own tile count: (a) all waves execute the same number of barriers, (b) every tile a half reads
+    was requested BEFORE an earlier barrier of that wave (so its vmcnt(0) + the barrier made it visible), (c) a request never
+    overwrites a stage that some wave may still read, (d) no tile past the stream's end is requested."""
+    STAGES = 8
+    passes = [n for n in (n1, n2) if True][: (2 if n2 > 0 else 1)]
+    total = sum(passes)
+
+    def wave_events(late, n_w_per_pass):
+        """-> list of events in program order: ("sync",) | ("read", virtual_tile) ; sync = vmcnt(0) + barrier + 2 requests"""
+        ev, tbase = [], 0
+        for pi, n_tiles in enumerate(passes):
+            n_w = min(n_w_per_pass[pi], n_tiles)
+            ev.append(("pass_start", tbase, n_tiles))
+            if n_w > 0:
+                ev.append(("read", tbase + 0))       # K(0): scores of tile 0
+                ev.append(("read", tbase + 1))       # K(1) fragments for iteration 0 (garbage if the pass has one tile)
+            for t in range(n_w):
+                even = (t % 2 == 0)
+                if late and even:
+                    ev.append(("sync",))
+                ev.append(("read", tbase + t))       # V(t) fragments, requested in the QK^T half
+                if (not late) and even:
+                    ev.append(("sync",))
+                ev.append(("read", tbase + t + 2))   # K(t+2) fragments, requested in the PV half
+            for t in range(n_w, n_tiles):
+                if t % 2 == 0:
+                    ev.append(("sync",))
+            tbase += n_tiles
+        return ev
+
+    # the shared (wave-uniform) request stream: what each sync / pass start requests
+    def requests():
+        out, vnext, vseen, tbase = [], 0, 0, 0    # out[k] = tiles requested at the k-th "request point"
+        pts = []
+        for pi, n_tiles in enumerate(passes):
+            nxt = passes[pi + 1] if pi + 1 < len(passes) else 0
+            first = []
+            while vnext < tbase + 4:
+                first.append(vnext); vnext += 1
+            need_barrier = vseen < tbase + 2
+            if need_barrier:
+                vseen = vnext
+            pts.append(("pass_start", [v for v in first if v - tbase < n_tiles + nxt], need_barrier))
+            for t in range(n_tiles):
+                if t % 2 == 0:
+                    vseen = vnext
+                    pts.append(("sync", [v for v in (vnext, vnext + 1) if v - tbase < n_tiles + nxt], True))
+                    vnext += 2
+            tbase += n_tiles
+        return pts
+
+    pts = requests()
+    assert all(v < total for _, vs, _ in pts for v in vs), "a tile past the end of the stream is requested"          # (d)
+    assert sorted(v for _, vs, _ in pts for v in vs) == list(range(total)), "every tile is requested exactly once"
+    n_sync = sum(1 for kind, _, _ in pts if kind == "sync")
+    waves = []
+    for late in (False, True):
+        for short in (0, 1, 2, 3):
+            n_w = [max(0, n - short) for n in passes]
+            ev = wave_events(late, n_w)
+            assert sum(1 for e in ev if e[0] == "sync") == n_sync                                                    # (a)
+            waves.append((late, ev))
+    # replay: global order = request points in sequence; a wave's reads between its (k)th and (k+1)th barrier-like point
+    for late, ev in waves:
+        k = -1                      # index of the last request point this wave has passed
+        visible = set()             # tiles requested before the last vmcnt(0)+barrier this wave executed
+        pending = set()             # requested by this wave since
+        pi = -1
+        for e in ev:
+            if e[0] == "pass_start":
+                k += 1
+                kind, vs, barrier = pts[k]
+                assert kind == "pass_start"
+                if barrier:
+                    pending |= set(vs); visible |= pending; pending = set()
+                else:
+                    pending |= set(vs)
+            elif e[0] == "sync":
+                k += 1
+                kind, vs, _ = pts[k]
+                assert kind == "sync"
+                visible |= pending; pending = set(vs)
+            else:
+                v = e[1]
+                if v < total:                                                                                      # (b)
+                    assert v in visible, f"late={late}: tile {v} read before a barrier made it visible"
+    # (c) WAR: when tile v is requested at request point k, every wave that could still read stage v % 8's previous
+    # occupant (tile v - 8) must have passed a barrier after its last read of it.  Waves are at most one barrier apart, so:
+    # the last read of tile v - 8 by ANY wave happens before that wave's barrier number (k - 1) at the latest.
+    order = {}
+    for late, ev in waves:
+        k = -1
+        for e in ev:
+            if e[0] in ("pass_start", "sync"):
+                k += 1
+            elif e[1] < total:
+                order[e[1]] = max(order.get(e[1], -1), k)   # read of tile happens after request point k of that wave
+    for k, (_, vs, _) in enumerate(pts):
+        for v in vs:
+            if v - STAGES >= 0 and (v - STAGES) in order:
+                # a wave issuing request point k has passed barrier k; another wave may still be before ITS point k only if
+                # point k is a barrier for it too (then it has arrived); reads recorded "after point j" with j <= k - 1 are done
+                assert order[v - STAGES] <= k - 1, f"tile {v} overwrites tile {v - STAGES} that may still be read"
