@@ -69,7 +69,8 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
   }
   const int b = bh / p.H, head = bh % p.H;
   const int kvh = head / (p.H / p.Hkv);
-  const X8 ones = __builtin_bit_cast(X8, (u32x4_t){pack2<T>(1.f, 1.f), pack2<T>(1.f, 1.f), pack2<T>(1.f, 1.f), pack2<T>(1.f, 1.f)});
+  X8 ones = __builtin_bit_cast(X8, (u32x4_t){pack2<T>(1.f, 1.f), pack2<T>(1.f, 1.f), pack2<T>(1.f, 1.f), pack2<T>(1.f, 1.f)});
+  asm volatile("" : "+v"(ones));  // stays in four VGPRs (hipcc otherwise rebuilds it from SGPRs in front of every row-sum pair)
 
   // per-lane LDS read offsets
   int k_rd[NDS];  // K fragment (kt, ds): row 16 kt + c16, chunk 4 ds + g at position (4 ds + g) ^ ((c16 >> 1) & 7)
@@ -406,6 +407,8 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       if constexpr (STAMP) c2 = __builtin_amdgcn_s_memtime();
       if constexpr (ABL & 1) asm volatile("" ::"v"(orw));
       else if (__builtin_expect(__builtin_amdgcn_ballot_w64((orw & 0x40004000u) != 0u) != 0 || fresh_any, 0)) move_ref(CB_, IC(1));
+      // one register home for the C-operand tuples on both paths (hipcc otherwise copies them on the COMMON path)
+      asm volatile("" : "+v"(nref4[0]), "+v"(nref4[1]));
       if (__builtin_expect(has_next && is_edge(t + 1), 0)) mask_tile(IC(cb ^ 1), (t + 1) * FA_BN);
       if constexpr (STAMP) c3 = __builtin_amdgcn_s_memtime();
       if constexpr (FA5_STAGGER) {
