@@ -94,8 +94,9 @@ typedef struct {
 } mio_fa3_fwd_params_t;
 
 int mio_fa3_fwd(const mio_fa3_fwd_params_t* p, void* stream);
-/* 1 iff a launch with these parameters (k_prescaled ignored) may set k_prescaled = 1: no user mask, no
- * (o_acc, lse) carry, Sq > 128, K / V rows within 4 GiB of their (batch, head) base, head dim <= 96. */
+/* 1 iff a launch with these parameters (k_prescaled ignored) may set k_prescaled = 1: no user mask, Sq > 128, K / V rows
+ * within 4 GiB of their (batch, head) base, head dim <= 96; with the (o_acc, lse) ring carry (o_acc and lse given,
+ * carry_in 0 / 1, o optional) only at head dim <= 64. */
 int32_t mio_fa3_k_prescaled_ok(const mio_fa3_fwd_params_t* p);
 
 /* Merge two normalised partial attention states over disjoint key sets (ring / split-KV):

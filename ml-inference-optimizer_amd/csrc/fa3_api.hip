@@ -15,8 +15,10 @@ static bool strides_ok(const int64_t s[3]) { return (s[0] % 8 == 0) && (s[1] % 8
 extern "C" int32_t mio_fa3_k_prescaled_ok(const mio_fa3_fwd_params_t* a) {
   if (a == nullptr) return 0;
   const bool span32 = (int64_t)a->Sk * a->k_stride[1] * 2 < (1ll << 32) && (int64_t)a->Sk * a->v_stride[1] * 2 < (1ll << 32);
-  return (a->D <= 96 && a->mask_kind == MIO_MASK_NONE && a->Sq > 128 && span32 && a->o != nullptr && a->o_acc == nullptr &&
-          !a->carry_in) ? 1 : 0;
+  if (!(a->D <= 96 && a->mask_kind == MIO_MASK_NONE && a->Sq > 128 && span32)) return 0;
+  const bool plain = a->o != nullptr && a->o_acc == nullptr && !a->carry_in;
+  // the (o_acc, lse) ring carry: fa3_fwd5_kernel only (head dim <= 64)
+  return (plain || (a->D <= 64 && a->o_acc != nullptr && a->lse != nullptr)) ? 1 : 0;
 }
 
 extern "C" int mio_fa3_fwd(const mio_fa3_fwd_params_t* a, void* stream) {

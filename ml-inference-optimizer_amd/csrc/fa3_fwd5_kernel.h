@@ -41,7 +41,8 @@ constexpr int FA5_STAGES = 8;
 constexpr bool FA5_STAGGER = true;
 constexpr int FA5_SMEM = FA5_STAGES * FA4_STAGE;
 
-template <typename T, bool CAUSAL, bool STAMP = false, int ABL = 0>  // ABL: timing-only ablations of the diagnostic build
+// CARRY: the ring form -- (o_acc fp32 [B, Sq, H, D], lse) carried in (p.carry_in) and written back; p.o may be null.
+template <typename T, bool CAUSAL, bool STAMP = false, int ABL = 0, bool CARRY = false>  // ABL: timing-only ablations (diagnostic build)
 __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
   using X8 = typename DT<T>::x8;
   using X4 = typename DT<T>::x4;
@@ -233,6 +234,30 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
     bool fresh_any = true;
     uint32_t orw = 0u;
     f32x4_t nref4[NQG] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+    if constexpr (CARRY) {
+      // a carried row continues from (o_acc, lse): reference = lse in base 2 (every earlier score lies below it), row sum 1,
+      // O = the normalised carry; rows that have seen no key yet (lse = -inf) start fresh
+      if (p.carry_in) {
+#pragma unroll
+        for (int qg = 0; qg < NQG; ++qg) {
+          const float lse_in = q_ok[qg] ? p.lse[((int64_t)b * p.H + head) * p.Sq + qrow[qg]] : -INFINITY;
+          if (lse_in != -INFINITY) {
+            ref[qg] = lse_in * FA_LOG2E;
+            fresh[qg] = false;
+            L[qg] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
+            const float* oa = p.o_acc + (((int64_t)b * p.Sq + qrow[qg]) * p.H + head) * p.D;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+              const int d0 = 16 * dt + 4 * g;
+              if (d0 < p.D) O[dt][qg] = *(const f32x4_t*)(oa + d0);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) nref4[qg][i] = -ref[qg];
+        }
+        fresh_any = __builtin_amdgcn_ballot_w64(fresh[0] || fresh[1]) != 0;
+      }
+    }
 
     f32x4_t S[2][NKT][NQG];  // score tiles: buffer (t & 1), 16-key tile, query group
     u32x4_t pfw[NS][NQG];    // P^T fragments: 32-key step s, query group
@@ -349,7 +374,7 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           nref4[qg][i] = -ref[qg];
-          if constexpr (WHEN != 0) {  // (tile 0: every row is fresh, O and L are still zero)
+          if constexpr (WHEN != 0 || CARRY) {  // (tile 0 without a carry: every row is fresh, O and L are still zero)
             L[qg][i] *= alpha;
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) O[dt][qg][i] *= alpha;
@@ -456,12 +481,25 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
         const float lse = (l_tot > 0.f) ? (ref[qg] + fast_log2(l_tot)) * FA_LN2 : -INFINITY;
         p.lse[((int64_t)b * p.H + head) * p.Sq + qrow[qg]] = lse;
       }
-      T* op = (T*)p.o + b * p.os_b + head * p.os_h + (int64_t)(q_ok[qg] ? qrow[qg] : 0) * p.os_s;
+      if (!CARRY || p.o != nullptr) {
+        T* op = (T*)p.o + b * p.os_b + head * p.os_h + (int64_t)(q_ok[qg] ? qrow[qg] : 0) * p.os_s;
 #pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-        const int d0 = 16 * dt + 4 * g;
-        const u32x2_t w = {pack2<T>(O[dt][qg][0] * inv, O[dt][qg][1] * inv), pack2<T>(O[dt][qg][2] * inv, O[dt][qg][3] * inv)};
-        if (q_ok[qg] && d0 < p.D) *(u32x2_t*)(op + d0) = w;
+        for (int dt = 0; dt < NDT; ++dt) {
+          const int d0 = 16 * dt + 4 * g;
+          const u32x2_t w = {pack2<T>(O[dt][qg][0] * inv, O[dt][qg][1] * inv), pack2<T>(O[dt][qg][2] * inv, O[dt][qg][3] * inv)};
+          if (q_ok[qg] && d0 < p.D) *(u32x2_t*)(op + d0) = w;
+        }
+      }
+      if constexpr (CARRY) {
+        if (p.o_acc != nullptr) {
+          float* oa = p.o_acc + (((int64_t)b * p.Sq + (q_ok[qg] ? qrow[qg] : 0)) * p.H + head) * p.D;
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            const f32x4_t w = {O[dt][qg][0] * inv, O[dt][qg][1] * inv, O[dt][qg][2] * inv, O[dt][qg][3] * inv};
+            if (q_ok[qg] && d0 < p.D) *(f32x4_t*)(oa + d0) = w;
+          }
+        }
       }
     }
     if constexpr (STAMP) st_all[11] += __builtin_amdgcn_s_memtime();

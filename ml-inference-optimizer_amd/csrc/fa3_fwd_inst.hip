@@ -162,13 +162,14 @@ static int launch_four(FaDev p, hipStream_t stream) {
 
 // fifth structure (fa3_fwd4's skeleton on 16x16x32 MFMA tiles): k_prescaled launches, head dim <= 64
 #if FA_D == 64
-template <bool CAUSAL>
+template <bool CAUSAL, bool CARRY = false>
 static int launch_five(FaDev p, hipStream_t stream) {
   p.nqblk = (p.Sq + FA4_BM - 1) / FA4_BM;
   p.qgrid = CAUSAL ? (p.nqblk + 1) / 2 : p.nqblk;
   const int grid = p.qgrid * p.B * p.H;
-  void (*kern)(const FaDev) = fa3_fwd5_kernel<FaT, CAUSAL>;
+  void (*kern)(const FaDev) = fa3_fwd5_kernel<FaT, CAUSAL, false, 0, CARRY>;
 #if defined(MIO_DIAG) && FA_TYPE_ID == 0
+  if constexpr (!CARRY) {
   p.xcd_remap |= (mio_dbg_get(3) & 3) << 4;  // wave-priority probe (tools/fa5_ablate.py)
   static const char* dbg_ptr = std::getenv("MIO_FA_DBG_PTR");  // in-kernel phase stamps (tools/fa5_stamps.py)
   if (dbg_ptr != nullptr) {
@@ -195,6 +196,7 @@ static int launch_five(FaDev p, hipStream_t stream) {
       hipLaunchKernelGGL(ka, dim3(grid), dim3(512), FA5_SMEM, stream, p);
       return 0;
     }
+  }
   }
 #endif
   static std::once_flag once;
@@ -238,6 +240,9 @@ int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t
     // k_prescaled (mio_fa3_fwd has checked mio_fa3_k_prescaled_ok), head dim <= 64: fa3_fwd5 (16x16x32 MFMA tiles).  Same
     // box, interleaved, B8 S4096 H16 bf16: causal 0.3047 ms vs 0.3305 fa3_fwd4 KPRE / 0.3401 fa3_fwd3 KPRE / 0.3570 fa3_fwd3;
     // non-causal 0.5494 vs 0.6162 / 0.5862 / 0.6273.  Diagnostic build: mio_dbg_set(1, 3 | 4) select the other KPRE forms.
+    // ... and its ring form: (o_acc, lse) carried in / written back, bf16 output optional
+    if (p.k_prescaled && !plain && mask_kind == MIO_MASK_NONE && p.Sq > 128 && span32 && p.o_acc != nullptr)
+      return causal ? launch_five<true, true>(p, stream) : launch_five<false, true>(p, stream);
     if (p.k_prescaled && plain) {
       int which = 5;
 #ifdef MIO_DIAG

@@ -199,7 +199,8 @@ def fa3_fwd(
     p.q_offset, p.k_offset, p.softmax_scale = int(q_offset), int(k_offset), scale
     if k_prescaled:
         if not lib.mio_fa3_k_prescaled_ok(C.byref(p)):
-            raise ValueError("k_prescaled is only supported for head_dim <= 96, no mask, no (o_acc, lse) carry, Sq > 128")
+            raise ValueError("k_prescaled is only supported for head_dim <= 96 (<= 64 with the (o_acc, lse) carry), no mask, "
+                             "Sq > 128")
         p.k_prescaled = 1
     check(lib.mio_fa3_fwd(C.byref(p), _stream()))
     if return_lse:
@@ -207,9 +208,12 @@ def fa3_fwd(
     return out
 
 
-def fa3_k_prescaled_ok(B: int, Sq: int, Sk: int, H: int, D: int, k_row_stride: int, v_row_stride: int) -> bool:
-    """True iff fa3_fwd(..., k_prescaled=True) is available for a plain (no mask, no carry) launch of this geometry."""
-    return D <= 96 and Sq > 128 and Sk * k_row_stride * 2 < (1 << 32) and Sk * v_row_stride * 2 < (1 << 32)
+def fa3_k_prescaled_ok(B: int, Sq: int, Sk: int, H: int, D: int, k_row_stride: int, v_row_stride: int,
+                       carry: bool = False) -> bool:
+    """True iff fa3_fwd(..., k_prescaled=True) is available for a launch of this geometry without a mask (carry: with the
+    (o_acc, lse) ring carry)."""
+    return (D <= (64 if carry else 96) and Sq > 128 and Sk * k_row_stride * 2 < (1 << 32)
+            and Sk * v_row_stride * 2 < (1 << 32))
 
 
 def _canon_mask4(mask: torch.Tensor) -> torch.Tensor:

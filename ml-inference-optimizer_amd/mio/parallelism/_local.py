@@ -10,8 +10,30 @@ from __future__ import annotations
 from .. import ops
 
 
-def linear(x, weight, bias=None, activation="none", residual=None, out=None):
+_blocked = {}  # (data_ptr, version, shape, dtype) -> blocked copy of a weight (col_scale launches take blocked weights)
+
+
+def _blocked_weight(w):
+    key = (w.data_ptr(), w._version, tuple(w.shape), w.dtype)
+    wb = _blocked.get(key)
+    if wb is None:
+        if len(_blocked) > 64:
+            _blocked.clear()
+        wb = _blocked[key] = ops.block_weight(w.detach())
+    return wb
+
+
+def linear(x, weight, bias=None, activation="none", residual=None, out=None, col_scale=None):
+    """col_scale = (lo, hi, value): see ops.gemm_bias_act (only where k_prescale_ok() said yes)."""
+    if col_scale is not None:
+        return ops.gemm_bias_act(x, weight, bias, activation, out=out, w_blocked=_blocked_weight(weight), col_scale=col_scale)
     return ops.gemm_bias_act(x, weight, bias, activation, residual=residual, out=out)
+
+
+def k_prescale_ok(B, Sq, H, D, M, N, K):
+    """True iff the K projection ([M, K] x [N, K]^T) can scale its columns in its epilogue AND the ring's attention launches
+    ((o_acc, lse) carry, Sq query rows per launch, head dim D) take pre-scaled K."""
+    return ops.col_scale_ok(M, N, K) and ops.fa3_k_prescaled_ok(B, Sq, Sq, H, D, H * D, H * D, carry=True)
 
 
 def attention_step(q, k, v, **kw):

@@ -113,7 +113,7 @@ def zigzag_unshard(shards: List[torch.Tensor], sp: int, seq_dim: int = 1) -> tor
 def ring_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, group: Optional[dist.ProcessGroup] = None, *,
                    layout: str = "bhsd", causal: bool = False, zigzag: bool = False, exchange: str = "mesh",
                    softmax_scale: Optional[float] = None, additive_mask: Optional[torch.Tensor] = None,
-                   recv_buffers: Optional[dict] = None, overlap: bool = True) -> torch.Tensor:
+                   recv_buffers: Optional[dict] = None, overlap: bool = True, k_prescaled: bool = False) -> torch.Tensor:
     """Exact attention of the local queries over the K/V shards of every rank in `group`.
 
     q/k/v are this rank's shards ([B,H,S/sp,D] for "bhsd", [B,S/sp,H,D] for "bshd"); returns the local
@@ -122,6 +122,7 @@ def ring_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, group: Opt
     [B,1|H,Sq_local,S_total], columns in global key order.  recv_buffers: a dict kept by the caller between calls --
     the mesh exchange then reuses its receive buffers instead of allocating sp - 1 K/V copies per call.
     overlap=False (measurement only): every transfer completes before the attention that could have hidden it starts.
+    k_prescaled: the K shards (local and travelling) already hold K * softmax_scale * log2(e) (ops.fa3_fwd k_prescaled).
     """
     sp = comm.get_world_size(group) if dist.is_initialized() else 1
     r = comm.get_rank(group) if dist.is_initialized() else 0
@@ -181,6 +182,8 @@ def ring_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, group: Opt
                 kw["out"] = out.narrow(si, qs, qn)
             if additive_mask is not None:
                 kw["additive_mask"] = additive_mask[..., koff:koff + kn]
+            if k_prescaled:
+                kw["k_prescaled"] = True
             _local.attention_step(q.narrow(si, qs, qn), kc.narrow(si, ks, kn), vc.narrow(si, ks, kn), **kw)
             states[qi] = (o_acc, lse, True)
 
@@ -253,11 +256,16 @@ class SequenceParallelAttention(nn.Module):
             hidden_states = _local.layernorm(hidden_states, pre_norm.weight, pre_norm.bias, pre_norm.eps)
         B, Sl, _ = hidden_states.shape
         H, D = self.num_attention_heads, self.head_dim
-        q = _local.linear(hidden_states, self.query.weight, self.query.bias).view(B, Sl, H, D)
-        k = _local.linear(hidden_states, self.key.weight, self.key.bias).view(B, Sl, H, D)
-        v = _local.linear(hidden_states, self.value.weight, self.value.bias).view(B, Sl, H, D)
         cfg = self.config
         mode = cfg.attention_handling
+        q = _local.linear(hidden_states, self.query.weight, self.query.bias).view(B, Sl, H, D)
+        # ring mode: the K projection scales its columns by softmax_scale * log2(e) in fp32 before their one rounding, and
+        # every ring step's attention launch drops its per-score multiply (ops.fa3_fwd k_prescaled) -- where both ends can
+        kpre = (mode == "ring" and cfg.sp_size > 1 and attention_mask is None
+                and _local.k_prescale_ok(B, Sl // (2 if cfg.zigzag else 1), H, D, B * Sl, H * D, hidden_states.shape[-1]))
+        kcs = (0, H * D, D ** -0.5 * 1.4426950408889634) if kpre else None
+        k = _local.linear(hidden_states, self.key.weight, self.key.bias, col_scale=kcs).view(B, Sl, H, D)
+        v = _local.linear(hidden_states, self.value.weight, self.value.bias).view(B, Sl, H, D)
         if mode == "local" or cfg.sp_size == 1:
             kw = dict(layout="bshd", causal=cfg.causal)
             if attention_mask is not None:
@@ -265,7 +273,8 @@ class SequenceParallelAttention(nn.Module):
             ctx = _local.attention_step(q, k, v, **kw)
         elif mode == "ring":
             ctx = ring_attention(q, k, v, self.sp_group, layout="bshd", causal=cfg.causal, zigzag=cfg.zigzag,
-                                 exchange=cfg.exchange, additive_mask=attention_mask, recv_buffers=self._recv_buffers)
+                                 exchange=cfg.exchange, additive_mask=attention_mask, recv_buffers=self._recv_buffers,
+                                 k_prescaled=kpre)
         else:  # "full": all-gather K/V then one exact attention (reference :587-640)
             t0 = time.perf_counter()
             kf = comm.all_gather(k, dim=1, group=self.sp_group)

@@ -12,9 +12,12 @@ _ACTS = {"none": lambda x: x, "gelu": gelu_tanh, "gelu_erf": torch.nn.functional
          "relu": torch.relu, "silu": torch.nn.functional.silu}
 
 
-def linear(x, weight, bias=None, activation="none", residual=None, out=None):
+def linear(x, weight, bias=None, activation="none", residual=None, out=None, col_scale=None):
     y = torch.nn.functional.linear(x.double(), weight.double(), None if bias is None else bias.double())
     y = _ACTS[activation](y)
+    if col_scale is not None:  # (lo, hi, value): scaled before the one rounding to the storage dtype
+        lo, hi, val = col_scale
+        y[..., lo:hi] = y[..., lo:hi] * val
     if residual is not None:
         y = y + residual.double()
     y = y.to(x.dtype)
@@ -26,7 +29,10 @@ def linear(x, weight, bias=None, activation="none", residual=None, out=None):
 
 def attention_step(q, k, v, *, layout="bshd", causal=False, softmax_scale=None, keep_mask=None, additive_mask=None,
                    return_lse=False, out=None, o_acc=None, lse=None, carry_in=False, write_out=True, q_offset=0,
-                   k_offset=0):
+                   k_offset=0, k_prescaled=False):
+    if k_prescaled:  # k already holds K * softmax_scale * log2(e): scores = q . k~ in base 2
+        import math
+        softmax_scale = math.log(2.0)
     if layout == "bhsd":
         qs, ks, vs = (t.permute(0, 2, 1, 3) for t in (q, k, v))
     else:
@@ -55,13 +61,19 @@ def layernorm(x, weight, bias=None, eps=1e-5):
     return oracle.layernorm(x, weight, bias, eps).to(x.dtype)
 
 
+def k_prescale_ok(B, Sq, H, D, M, N, K):
+    return D <= 64  # (the HIP rule also wants Sq > 128 and a 256-tile GEMM shape; the schedule tests run smaller)
+
+
 def install(monkeypatch=None):
     from mio.parallelism import _local
     if monkeypatch is not None:
         monkeypatch.setattr(_local, "linear", linear)
         monkeypatch.setattr(_local, "attention_step", attention_step)
         monkeypatch.setattr(_local, "layernorm", layernorm)
+        monkeypatch.setattr(_local, "k_prescale_ok", k_prescale_ok)
     else:
         _local.linear = linear
         _local.attention_step = attention_step
         _local.layernorm = layernorm
+        _local.k_prescale_ok = k_prescale_ok

@@ -279,6 +279,46 @@ def test_fa3_carry_and_merge_roundtrip():
     assert (o4.float() - full.float()).abs().max() < 2e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,S,H,Hkv,D,causal", [(1, 640, 4, 4, 64, False), (2, 450, 4, 2, 64, True), (1, 832, 3, 3, 48, True)])
+def test_fa3_k_prescaled_carry(dtype, B, S, H, Hkv, D, causal):
+    """The ring form of the k_prescaled launch (fa3_fwd5_kernel CARRY): K~ / V shards visited in ring order -- the local
+    (diagonal) shard first, then the past ones -- with the (o_acc fp32, lse) state carried from launch to launch, a shard in
+    the future of every query dropped by the kernel (state untouched), the last launch writing the 16-bit output.  Against
+    the oracle's whole attention on (q, K~, v) in base 2."""
+    import math
+    ops = _ops()
+    torch.manual_seed(S + D + int(causal))
+    q = (torch.randn(B, S, H, D) * 2).to(dtype)
+    kt = (torch.randn(B, S, Hkv, D) * (math.log2(math.e) / math.sqrt(D))).to(dtype)
+    v = torch.randn(B, S, Hkv, D).to(dtype)
+    ref, rlse = oracle.attention_with_lse(q, kt, v, causal=causal, softmax_scale=math.log(2.0))
+    qd, kd, vd = q.to(DEV), kt.to(DEV), v.to(DEV)
+    assert ops.fa3_k_prescaled_ok(B, S - 2 * (S // 3), S // 3, H, D, Hkv * D, Hkv * D, carry=True)
+    # queries = the LAST third of the sequence (a rank's shard), keys in three shards: own, then the two before it
+    n = S // 3
+    qs = qd[:, 2 * n:].contiguous()
+    Sq = qs.shape[1]
+    o_acc = torch.zeros(B, Sq, H, D, dtype=torch.float32, device=DEV)
+    lse = torch.full((B, H, Sq), float("-inf"), device=DEV)
+    out = torch.empty_like(qs)
+    order = [(2 * n, S), (n, 2 * n), (0, n)]
+    for i, (a, b) in enumerate(order):
+        ops.fa3_fwd(qs, kd[:, a:b].contiguous(), vd[:, a:b].contiguous(), causal=causal, q_offset=2 * n if causal else 0,
+                    k_offset=a if causal else 0, o_acc=o_acc, lse=lse, carry_in=(i > 0), write_out=(i == 2), out=out,
+                    k_prescaled=True)
+    _cmp(out.cpu(), ref[:, 2 * n:], dtype, "o")
+    assert (o_acc.cpu().double() - ref[:, 2 * n:]).abs().max() < (1.5e-2 if dtype == torch.bfloat16 else 3e-3)
+    assert (lse.cpu().double() - rlse[:, :, 2 * n:]).abs().max() < (6e-3 if dtype == torch.bfloat16 else 2e-3)
+    if causal:  # the FIRST third as queries against the last shard: every key lies in the future, the state must not move
+        q1 = qd[:, :n + 40].contiguous()
+        o1 = torch.full((B, n + 40, H, D), 3.0, dtype=torch.float32, device=DEV)
+        l1 = torch.full((B, H, n + 40), 0.25, device=DEV)
+        ops.fa3_fwd(q1, kd[:, 2 * n:].contiguous(), vd[:, 2 * n:].contiguous(), causal=True, q_offset=0, k_offset=2 * n,
+                    o_acc=o1, lse=l1, carry_in=True, write_out=False, k_prescaled=True)
+        assert (o1 - 3.0).abs().max() < 1e-5 and (l1 - 0.25).abs().max() < 1e-5
+
+
 ACTS = ["gelu", "gelu_erf", "relu", "silu", "swiglu"]
 
 

@@ -40,14 +40,19 @@ def _run(fn_name, world=2, args=()):
     mp.spawn(_worker, args=(world, _free_port(), fn_name, args), nprocs=world, join=True)
 
 
-def _w_ring(rank, world, exchange, causal, zigzag, layout):
+def _w_ring(rank, world, exchange, causal, zigzag, layout, kpre=False):
+    import math
     import oracle
     from mio.parallelism.sequence_parallel import ring_attention, zigzag_shard
     torch.manual_seed(1)
     B, H, S, D = 1, 4, 512 * world, 64
     dt = torch.float16
     q, k, v = (torch.randn(B, S, H, D).to(dt) for _ in range(3))
-    ref = oracle.standard_attention(q, k, v, causal=causal)
+    if kpre:  # K as the projection's col_scale epilogue hands it over; the checker works on the same rounded K~ in base 2
+        k = (k.float() * (math.log2(math.e) / math.sqrt(D))).to(dt)
+        ref = oracle.attention_with_lse(q, k, v, causal=causal, softmax_scale=math.log(2.0))[0]
+    else:
+        ref = oracle.standard_attention(q, k, v, causal=causal)
     if zigzag:
         loc = [zigzag_shard(t, rank, world, 1) for t in (q, k, v)]
         ref_loc = zigzag_shard(ref, rank, world, 1)
@@ -56,7 +61,7 @@ def _w_ring(rank, world, exchange, causal, zigzag, layout):
         loc = [t[:, rank * n:(rank + 1) * n] for t in (q, k, v)]
         ref_loc = ref[:, rank * n:(rank + 1) * n]
     loc = [(t.permute(0, 2, 1, 3) if layout == "bhsd" else t).contiguous().cuda() for t in loc]
-    out = ring_attention(*loc, None, layout=layout, causal=causal, zigzag=zigzag, exchange=exchange)
+    out = ring_attention(*loc, None, layout=layout, causal=causal, zigzag=zigzag, exchange=exchange, k_prescaled=kpre)
     out = out.cpu()
     if layout == "bhsd":
         out = out.permute(0, 2, 1, 3)
@@ -191,6 +196,13 @@ def _w_bench_extras(rank, world):
 ])
 def test_ring_attention_hip_ws2(exchange, causal, zigzag, layout):
     _run("_w_ring", 2, (exchange, causal, zigzag, layout))
+
+
+@pytest.mark.parametrize("exchange,causal,zigzag,layout", [("mesh", False, False, "bshd"), ("ring", True, True, "bhsd")])
+def test_ring_attention_k_prescaled_hip_ws2(exchange, causal, zigzag, layout):
+    """The same ring with pre-scaled K shards: every step is a k_prescaled launch with the (o_acc, lse) carry
+    (fa3_fwd5_kernel CARRY at head dim 64)."""
+    _run("_w_ring", 2, (exchange, causal, zigzag, layout, True))
 
 
 def test_tensor_parallel_hip_ws2():

@@ -96,7 +96,13 @@ def bench_ring(N, S_total, d, H, dt, steps=3, warmup=1):
     Sl = S_total // N
     torch.manual_seed(100 + dist.get_rank())
     q, k, v = (torch.randn(1, H, Sl, D, device="cuda", dtype=dt) for _ in range(3))
-    out = {}
+    # as SequenceParallelAttention hands it over in ring mode: K pre-scaled by its projection's epilogue where the launches
+    # support it (head dim <= 64: fa3_fwd5_kernel with the (o_acc, lse) carry)
+    from mio import ops
+    kpre = bool(ops.fa3_k_prescaled_ok(1, Sl // 2, Sl // 2, H, D, D, D, carry=True))
+    if kpre:
+        k = (k.float() * (D ** -0.5 * 1.4426950408889634)).to(dt)
+    out = {"k_prescaled": kpre}
     pool = {}
     for name, kw in (("noncausal_mesh", dict(exchange="mesh")),
                      ("noncausal_mesh_unoverlapped", dict(exchange="mesh", overlap=False)),
@@ -104,11 +110,11 @@ def bench_ring(N, S_total, d, H, dt, steps=3, warmup=1):
                      ("noncausal_ring_unoverlapped", dict(exchange="ring", overlap=False)),
                      ("causal_zigzag_mesh", dict(exchange="mesh", causal=True, zigzag=True))):
         for _ in range(warmup):
-            ring_attention(q, k, v, None, layout="bhsd", recv_buffers=pool, **kw)
+            ring_attention(q, k, v, None, layout="bhsd", recv_buffers=pool, k_prescaled=kpre, **kw)
         _sync()
         t0 = time.perf_counter()
         for _ in range(steps):
-            ring_attention(q, k, v, None, layout="bhsd", recv_buffers=pool, **kw)
+            ring_attention(q, k, v, None, layout="bhsd", recv_buffers=pool, k_prescaled=kpre, **kw)
         _sync()
         el = _max_over_ranks(time.perf_counter() - t0) / steps
         flops = 4.0 * S_total * S_total * d * (0.5 if "causal" in kw else 1.0)
