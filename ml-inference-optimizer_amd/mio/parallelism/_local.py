@@ -10,30 +10,37 @@ from __future__ import annotations
 from .. import ops
 
 
-_blocked = {}  # (data_ptr, version, shape, dtype) -> blocked copy of a weight (col_scale launches take blocked weights)
+import weakref
+
+_blocked = {}  # id(weight tensor) -> (weakref to it, version, blocked copy): the 256x256-tile GEMMs take blocked weights
 
 
 def _blocked_weight(w):
-    key = (w.data_ptr(), w._version, tuple(w.shape), w.dtype)
-    wb = _blocked.get(key)
-    if wb is None:
-        if len(_blocked) > 64:
-            _blocked.clear()
-        wb = _blocked[key] = ops.block_weight(w.detach())
+    hit = _blocked.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == w._version:
+        return hit[2]
+    if len(_blocked) > 256:
+        _blocked.clear()
+    wb = ops.block_weight(w.detach())
+    _blocked[id(w)] = (weakref.ref(w), w._version, wb)
     return wb
 
 
 def linear(x, weight, bias=None, activation="none", residual=None, out=None, col_scale=None):
-    """col_scale = (lo, hi, value): see ops.gemm_bias_act (only where k_prescale_ok() said yes)."""
-    if col_scale is not None:
-        return ops.gemm_bias_act(x, weight, bias, activation, out=out, w_blocked=_blocked_weight(weight), col_scale=col_scale)
-    return ops.gemm_bias_act(x, weight, bias, activation, residual=residual, out=out)
+    """F.linear (+ activation, + residual) on the MFMA GEMM; at sizes that run the 256x256-tile kernels the weight goes in
+    the blocked layout (repacked once per parameter version).  col_scale = (lo, hi, value): see ops.gemm_bias_act (only
+    where k_prescale_ok() said yes)."""
+    N, K = weight.shape
+    M = x.numel() // K
+    wb = _blocked_weight(weight) if (K % 32 == 0 and ops.blocked_weight_ok(M, N, K, activation)) else None
+    return ops.gemm_bias_act(x, weight, bias, activation, residual=residual, out=out, w_blocked=wb, col_scale=col_scale)
 
 
-def k_prescale_ok(B, Sq, H, D, M, N, K):
-    """True iff the K projection ([M, K] x [N, K]^T) can scale its columns in its epilogue AND the ring's attention launches
-    ((o_acc, lse) carry, Sq query rows per launch, head dim D) take pre-scaled K."""
-    return ops.col_scale_ok(M, N, K) and ops.fa3_k_prescaled_ok(B, Sq, Sq, H, D, H * D, H * D, carry=True)
+def k_prescale_ok(B, Sq, H, D, M, N, K, carry=True, row_stride=None):
+    """True iff the projection that produces K ([M, K] x [N, K]^T) can scale columns in its epilogue AND the attention launches
+    (Sq query rows per launch, head dim D; carry: with the ring's (o_acc, lse) state) take pre-scaled K."""
+    rs = H * D if row_stride is None else row_stride
+    return ops.col_scale_ok(M, N, K) and ops.fa3_k_prescaled_ok(B, Sq, Sq, H, D, rs, rs, carry=carry)
 
 
 def attention_step(q, k, v, **kw):

@@ -258,9 +258,14 @@ class TensorParallelAttention(nn.Module):
         kv_in = encoder_hidden_states if (self.is_cross_attention and encoder_hidden_states is not None) else hidden_states
         n = Hl * D
         Sk = kv_in.shape[1]
+        kpre = False
         if kv_in is hidden_states:  # self attention: one [3 n, hidden] GEMM, q / k / v are strided views of its result
             w, b = self._fused_weight(("query", "key", "value"))
-            qkv = _local.linear(hidden_states, w, b)
+            # where both kernels can: the K columns leave the GEMM multiplied by softmax_scale * log2(e) (one rounding) and
+            # the attention launch drops its per-score multiply (ops.fa3_fwd k_prescaled)
+            kpre = (attention_mask is None and n % 128 == 0
+                    and _local.k_prescale_ok(B, S, Hl, D, B * S, 3 * n, hidden_states.shape[-1], carry=False, row_stride=3 * n))
+            qkv = _local.linear(hidden_states, w, b, col_scale=(n, 2 * n, D ** -0.5 * 1.4426950408889634) if kpre else None)
             q, k, v = (qkv[..., i * n:(i + 1) * n].view(B, S, Hl, D) for i in range(3))
         else:
             q = self.query(hidden_states).view(B, S, Hl, D)
@@ -272,7 +277,8 @@ class TensorParallelAttention(nn.Module):
             add = attention_mask
             while add.dim() < 4:
                 add = add.unsqueeze(1)
-        ctx = _local.attention_step(q, k, v, layout="bshd", causal=self.causal, additive_mask=add)
+        ctx = _local.attention_step(q, k, v, layout="bshd", causal=self.causal, additive_mask=add,
+                                    **({"k_prescaled": True} if kpre else {}))
         return self.output(ctx.reshape(B, S, Hl * D), residual=residual)
 
 
