@@ -46,7 +46,7 @@ template <typename T, bool CAUSAL, bool STAMP = false, int ABL = 0, bool CARRY =
 __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
   using X8 = typename DT<T>::x8;
   using X4 = typename DT<T>::x4;
-  constexpr int NKT = 4, NQG = 2, NDS = 2, NDT = 4, NS = 2, UPW = 2;
+  constexpr int NKT = 4, NQG = 2, NDS = 2, NDT = 4, NS = 2;
 #define IC(N) std::integral_constant<int, (N)> {}
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
