@@ -211,7 +211,7 @@ def _attention_ref16(q, k, v, causal):
     return out
 
 
-def _attention_oracle_rows(name, o, lse, q, k, v, causal, n=ORACLE_ROWS, seed=0):
+def _attention_oracle_rows(name, o, lse, q, k, v, causal, n=ORACLE_ROWS, seed=0, softmax_scale=None):
     """oracle.attention_with_lse on sampled (batch, head, query row) triples: the query row against the keys it sees."""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
@@ -228,7 +228,7 @@ def _attention_oracle_rows(name, o, lse, q, k, v, causal, n=ORACLE_ROWS, seed=0)
         hk = h // (H // Hkv)
         nk = min(r + 1, Sk) if causal else Sk
         ref, rl = oracle.attention_with_lse(qc[b:b + 1, r:r + 1, h:h + 1], kc[b:b + 1, :nk, hk:hk + 1],
-                                            vc[b:b + 1, :nk, hk:hk + 1], causal=False)
+                                            vc[b:b + 1, :nk, hk:hk + 1], causal=False, softmax_scale=softmax_scale)
         got.append(oc[b, r, h].float())
         want.append(ref[0, 0, 0].to(o.dtype).float())
         dl = max(dl, abs(float(lc[b, h, r]) - float(rl[0, 0, 0])))
@@ -255,6 +255,39 @@ def test_c2_attention_b8_h16_s4096_causal():
     name = "c2_attention B8 H16 S4096 D64 causal"
     _record(name, o, truth, ref16)
     _attention_oracle_rows(name, o, lse, q, k, v, True)
+
+
+def test_c2_attention_b8_h16_s4096_causal_k_prescaled():
+    """The attention launch `bench.py` times: fa3_fwd5_kernel on the benchmark grid (B 8 x H 16 with the XCD remap, S 4096,
+    D 64, causal), q / K~ / v as strided views of the fused projection result whose K columns the GEMM epilogue scaled by
+    softmax_scale * log2(e) (col_scale, fp32, one rounding).  Truth = fp32 softmax of the UNSCALED k chain; the reference's
+    bf16 chain next to it; the oracle on sampled rows works on the rounded K~ in base 2."""
+    ops = _ops()
+    B, S, H, d = C2["B"], C2["S"], C2["H"], C2["d"]
+    D = d // H
+    (x,) = _c2_inputs(21, (B, S, d))
+    torch.manual_seed(22)
+    w = (torch.randn(3 * d, d) * 0.02).to(torch.bfloat16).to(DEV)
+    bias = (torch.randn(3 * d) * 0.02).to(torch.bfloat16).to(DEV)
+    M = B * S
+    assert ops.col_scale_ok(M, 3 * d, d) and ops.fa3_k_prescaled_ok(B, S, S, H, D, 3 * d, 3 * d)
+    c = D ** -0.5 * 1.4426950408889634
+    wb = ops.block_weight(w)
+    qkv = ops.gemm_bias_act(x, w, bias, w_blocked=wb)                                    # plain projection
+    qkv_s = ops.gemm_bias_act(x, w, bias, w_blocked=wb, col_scale=(d, 2 * d, c))        # K columns pre-scaled
+    q, k, v = (qkv[:, :, i * d:(i + 1) * d].view(B, S, H, D) for i in range(3))
+    qs, ks, vs = (qkv_s[:, :, i * d:(i + 1) * d].view(B, S, H, D) for i in range(3))
+    assert torch.equal(q, qs) and torch.equal(v, vs)
+    o, lse = ops.fa3_fwd(qs, ks, vs, causal=True, return_lse=True, k_prescaled=True)
+    # fp32 truth from the fp32 projection (k unrounded), the reference's bf16 chain from the bf16 projection
+    qkv32 = F.linear(x.float(), w.float(), bias.float())
+    q32, k32, v32 = (qkv32[:, :, i * d:(i + 1) * d].view(B, S, H, D) for i in range(3))
+    truth = _attention_truth(q.float(), k32, v.float(), True)   # q, v as the kernel sees them (16-bit), k exact
+    ref16 = _attention_ref16(q, k, v, True)
+    name = "c2_attention k_prescaled (fa3_fwd5) B8 H16 S4096 D64 causal"
+    _record(name, o, truth, ref16)
+    _attention_oracle_rows(name, o, lse, qs, ks, vs, True, softmax_scale=math.log(2.0))
+    del k32, q32, v32, qkv32
 
 
 def test_c2_block_b8_s4096():
