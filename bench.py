@@ -186,7 +186,8 @@ def c5_leg(dt, steps=3):
     x = torch.randn(B, S, d, device="cuda", dtype=dt)
     ctx = torch.randn(B, S, d, device="cuda", dtype=dt)
     with torch.no_grad():
-        model(x, ctx)
+        for _ in range(3):  # first calls: weight repack, hipFuncSetAttribute, (under rocprofv3) the tracer's first-launch work
+            model(x, ctx)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
