@@ -129,12 +129,19 @@ def kernel_rooflines(model, x, iters=10):
     q = qkv[:, :, :d].view(B, S, H, D)
     k = qkv[:, :, d:2 * d].view(B, S, H, D)
     v = qkv[:, :, 2 * d:].view(B, S, H, D)
-    ctx = ops.fa3_fwd(q, k, v, causal=True, k_prescaled=kpre).view(B, S, d)
-    att = ops.gemm_bias_act(ctx, wo, bo, residual=x)
+    # ... and where the output projection runs a 256-tile kernel the attention epilogue writes its result in that GEMM's blocked
+    # activation layout (ops.fa3_fwd out_blocked), again as FlashSelfAttention does
+    oblk = bool(kpre and ops.blocked_weight_ok(M, d, d) and ops.fa3_o_blocked_ok(B, S, S, H, D, 3 * d, 3 * d))
+    if oblk:
+        ctx = ops.fa3_fwd(q, k, v, causal=True, k_prescaled=True, out_blocked=True)
+        att = ops.gemm_bias_act(ctx, wo, bo, residual=x, w_blocked=wo_b, x_blocked_shape=(B, S, d))
+    else:
+        ctx = ops.fa3_fwd(q, k, v, causal=True, k_prescaled=kpre).view(B, S, d)
+        att = ops.gemm_bias_act(ctx, wo, bo, residual=x)
     ln2 = ops.layernorm(att, blk.ln_2.weight, blk.ln_2.bias)
     o3, o1 = torch.empty_like(qkv), torch.empty_like(att)
     out = {}
-    t = _events_ms(lambda: ops.fa3_fwd(q, k, v, causal=True, k_prescaled=kpre), iters)
+    t = _events_ms(lambda: ops.fa3_fwd(q, k, v, causal=True, k_prescaled=kpre, out_blocked=oblk), iters)
     out["fa3_fwd5_kernel<bf16,causal>" if kpre else "fa3_fwd4_kernel<bf16,causal>"] = dict(ms=t, launches=1, flops=2.0 * B * S * (S + 1) * d)
 
     t = _events_ms(lambda: ops.gemm_bias_act(ln1, wqkv, bqkv, out=o3, w_blocked=wqkv_b, col_scale=cs), iters)
@@ -143,7 +150,8 @@ def kernel_rooflines(model, x, iters=10):
     t = _events_ms(lambda: ops.fused_mlp(ln2, w1, b1, w2, b2, "gelu", residual=att, fc1_blocked=w1_b, fc2_blocked=w2_b), iters)
     out["fused_mlp: gemm4w16p_kernel<bf16,gelu_tanh> + gemm4w16_kernel<bf16,none>"] = dict(
         ms=t, launches=2, flops=4.0 * M * d * I, combined=True)  # two different kernels: not a roofline candidate
-    t = _events_ms(lambda: ops.gemm_bias_act(ctx, wo, bo, residual=x, out=o1, w_blocked=wo_b), iters)
+    t = _events_ms(lambda: ops.gemm_bias_act(ctx, wo, bo, residual=x, out=o1, w_blocked=wo_b,
+                                             x_blocked_shape=(B, S, d) if oblk else None), iters)
     out["gemm4w16_kernel<bf16,none> (out-proj)"] = dict(ms=t, launches=1, flops=2.0 * M * d * d)
     t = _events_ms(lambda: ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias), iters)
     out["layernorm_kernel<bf16>"] = dict(ms=2 * t, launches=2, bytes=2 * 2.0 * M * d * 2)

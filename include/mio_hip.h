@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MIO_VERSION 101 /* 0.1.0 */
+#define MIO_VERSION 102 /* 0.1.0 */
 
 typedef enum { MIO_BF16 = 0, MIO_FP16 = 1 } mio_dtype_t;
 
@@ -91,6 +91,9 @@ typedef struct {
   int32_t k_prescaled; /* 0/1: k already holds K * softmax_scale * log2(e), scaled in fp32 BEFORE its rounding to 16 bits
                           (mio_gemm_bias_act_bw col_scale: the epilogue of the projection that produced it).  Only for
                           launches mio_fa3_k_prescaled_ok() accepts; the kernel then skips the per-score multiply. */
+  int32_t o_blocked;   /* 0/1: `o` is the [B*Sq, H*D] output in the blocked ACTIVATION layout of the GEMM entry points below
+                          (ceil(B*Sq/256)*256 x H*D elements, o_stride ignored): the attention epilogue hands the output
+                          projection contiguous K-tiles.  Only for launches mio_fa3_o_blocked_ok() accepts. */
 } mio_fa3_fwd_params_t;
 
 int mio_fa3_fwd(const mio_fa3_fwd_params_t* p, void* stream);
@@ -98,6 +101,9 @@ int mio_fa3_fwd(const mio_fa3_fwd_params_t* p, void* stream);
  * within 4 GiB of their (batch, head) base, head dim <= 96; with the (o_acc, lse) ring carry (o_acc and lse given,
  * carry_in 0 / 1, o optional) only at head dim <= 64. */
 int32_t mio_fa3_k_prescaled_ok(const mio_fa3_fwd_params_t* p);
+/* 1 iff a launch with these parameters (o_blocked ignored) may set o_blocked = 1: a k_prescaled launch without the ring
+ * carry at head dim <= 64 with (H * D) % 32 == 0. */
+int32_t mio_fa3_o_blocked_ok(const mio_fa3_fwd_params_t* p);
 
 /* Merge two normalised partial attention states over disjoint key sets (ring / split-KV):
  * o = w_a*o_a + w_b*o_b, lse = logaddexp(lse_a, lse_b), w_x = exp(lse_x - lse).

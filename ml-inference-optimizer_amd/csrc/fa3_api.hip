@@ -21,6 +21,12 @@ extern "C" int32_t mio_fa3_k_prescaled_ok(const mio_fa3_fwd_params_t* a) {
   return (plain || (a->D <= 64 && a->o_acc != nullptr && a->lse != nullptr)) ? 1 : 0;
 }
 
+extern "C" int32_t mio_fa3_o_blocked_ok(const mio_fa3_fwd_params_t* a) {
+  if (a == nullptr || !mio_fa3_k_prescaled_ok(a)) return 0;
+  const bool plain = a->o != nullptr && a->o_acc == nullptr && !a->carry_in;
+  return (plain && a->D <= 64 && ((int64_t)a->H * a->D) % 32 == 0) ? 1 : 0;
+}
+
 extern "C" int mio_fa3_fwd(const mio_fa3_fwd_params_t* a, void* stream) {
   MIO_CHECK(a != nullptr, "mio_fa3_fwd: null params");
   MIO_CHECK(a->q && a->k && a->v, "mio_fa3_fwd: q/k/v must be non-null");
@@ -33,7 +39,7 @@ extern "C" int mio_fa3_fwd(const mio_fa3_fwd_params_t* a, void* stream) {
   MIO_CHECK(a->mask_kind >= 0 && a->mask_kind <= 2, "mio_fa3_fwd: bad mask_kind");
   MIO_CHECK((a->mask_kind == MIO_MASK_NONE) == (a->mask == nullptr), "mio_fa3_fwd: mask pointer / mask_kind mismatch");
   MIO_CHECK(strides_ok(a->q_stride) && strides_ok(a->k_stride) && strides_ok(a->v_stride) &&
-                (a->o == nullptr || strides_ok(a->o_stride)),
+                (a->o == nullptr || a->o_blocked || strides_ok(a->o_stride)),
             "mio_fa3_fwd: strides must be multiples of 8 elements (16-byte rows)");
   MIO_CHECK(mio_aligned16(a->q) && mio_aligned16(a->k) && mio_aligned16(a->v) && mio_aligned16(a->o) &&
                 mio_aligned16(a->o_acc),
@@ -56,6 +62,9 @@ extern "C" int mio_fa3_fwd(const mio_fa3_fwd_params_t* a, void* stream) {
   p.xcd_remap = ((a->B * a->H) % 8 == 0) ? 1 : 0;
   p.scale_log2e = a->softmax_scale * FA_LOG2E;
   p.k_prescaled = a->k_prescaled ? 1 : 0;
+  p.o_blk = a->o_blocked ? 1 : 0;
+  MIO_CHECK(!p.o_blk || (p.k_prescaled && mio_fa3_o_blocked_ok(a)), "mio_fa3_fwd: o_blocked is not supported for this launch "
+                                                                     "(needs k_prescaled and mio_fa3_o_blocked_ok != 0)");
   MIO_CHECK(!p.k_prescaled || mio_fa3_k_prescaled_ok(a), "mio_fa3_fwd: k_prescaled is not supported for this launch "
                                                          "(mio_fa3_k_prescaled_ok == 0)");
 

@@ -42,7 +42,8 @@ constexpr bool FA5_STAGGER = true;
 constexpr int FA5_SMEM = FA5_STAGES * FA4_STAGE;
 
 // CARRY: the ring form -- (o_acc fp32 [B, Sq, H, D], lse) carried in (p.carry_in) and written back; p.o may be null.
-template <typename T, bool CAUSAL, bool STAMP = false, int ABL = 0, bool CARRY = false>  // ABL: timing-only ablations (diagnostic build)
+// OBLK: the 16-bit output goes to the GEMMs' blocked activation layout (FaDev::o_blk launches; not with CARRY).
+template <typename T, bool CAUSAL, bool STAMP = false, int ABL = 0, bool CARRY = false, bool OBLK = false>  // ABL: timing-only ablations (diagnostic build)
 __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
   using X8 = typename DT<T>::x8;
   using X4 = typename DT<T>::x4;
@@ -482,12 +483,25 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
         p.lse[((int64_t)b * p.H + head) * p.Sq + qrow[qg]] = lse;
       }
       if (!CARRY || p.o != nullptr) {
-        T* op = (T*)p.o + b * p.os_b + head * p.os_h + (int64_t)(q_ok[qg] ? qrow[qg] : 0) * p.os_s;
+        if constexpr (OBLK) {
+          // element (m, c) of the [B*Sq, H*D] matrix in the GEMMs' blocked activation layout:
+          // ((m / 256) * (H*D / 32) + c / 32) * 16 KiB + (m % 256) * 64 B + (c % 32) * 2 B
+          const int64_t m = (int64_t)b * p.Sq + (q_ok[qg] ? qrow[qg] : 0);
+          char* ob = (char*)p.o + (((m >> 8) * ((p.H * p.D) >> 5)) << 14) + ((m & 255) << 6);
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-          const int d0 = 16 * dt + 4 * g;
-          const u32x2_t w = {pack2<T>(O[dt][qg][0] * inv, O[dt][qg][1] * inv), pack2<T>(O[dt][qg][2] * inv, O[dt][qg][3] * inv)};
-          if (q_ok[qg] && d0 < p.D) *(u32x2_t*)(op + d0) = w;
+          for (int dt = 0; dt < NDT; ++dt) {
+            const int d0 = 16 * dt + 4 * g, c = head * p.D + d0;
+            const u32x2_t w = {pack2<T>(O[dt][qg][0] * inv, O[dt][qg][1] * inv), pack2<T>(O[dt][qg][2] * inv, O[dt][qg][3] * inv)};
+            if (q_ok[qg] && d0 < p.D) *(u32x2_t*)(ob + ((int64_t)(c >> 5) << 14) + ((c & 31) << 1)) = w;
+          }
+        } else {
+          T* op = (T*)p.o + b * p.os_b + head * p.os_h + (int64_t)(q_ok[qg] ? qrow[qg] : 0) * p.os_s;
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            const u32x2_t w = {pack2<T>(O[dt][qg][0] * inv, O[dt][qg][1] * inv), pack2<T>(O[dt][qg][2] * inv, O[dt][qg][3] * inv)};
+            if (q_ok[qg] && d0 < p.D) *(u32x2_t*)(op + d0) = w;
+          }
         }
       }
       if constexpr (CARRY) {

@@ -162,14 +162,14 @@ static int launch_four(FaDev p, hipStream_t stream) {
 
 // fifth structure (fa3_fwd4's skeleton on 16x16x32 MFMA tiles): k_prescaled launches, head dim <= 64
 #if FA_D == 64
-template <bool CAUSAL, bool CARRY = false>
+template <bool CAUSAL, bool CARRY = false, bool OBLK = false>
 static int launch_five(FaDev p, hipStream_t stream) {
   p.nqblk = (p.Sq + FA4_BM - 1) / FA4_BM;
   p.qgrid = CAUSAL ? (p.nqblk + 1) / 2 : p.nqblk;
   const int grid = p.qgrid * p.B * p.H;
-  void (*kern)(const FaDev) = fa3_fwd5_kernel<FaT, CAUSAL, false, 0, CARRY>;
+  void (*kern)(const FaDev) = fa3_fwd5_kernel<FaT, CAUSAL, false, 0, CARRY, OBLK>;
 #if defined(MIO_DIAG) && FA_TYPE_ID == 0
-  if constexpr (!CARRY) {
+  if constexpr (!CARRY && !OBLK) {
   p.xcd_remap |= (mio_dbg_get(3) & 3) << 4;  // wave-priority probe (tools/fa5_ablate.py)
   static const char* dbg_ptr = std::getenv("MIO_FA_DBG_PTR");  // in-kernel phase stamps (tools/fa5_stamps.py)
   if (dbg_ptr != nullptr) {
@@ -248,6 +248,7 @@ int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t
 #ifdef MIO_DIAG
       if (mio_dbg_get(1) == 3 || mio_dbg_get(1) == 4) which = mio_dbg_get(1);
 #endif
+      if (which == 5 && p.o_blk) return causal ? launch_five<true, false, true>(p, stream) : launch_five<false, false, true>(p, stream);
       if (which == 5) return causal ? launch_five<true>(p, stream) : launch_five<false>(p, stream);
 #ifdef MIO_DIAG
       if (which == 4) return causal ? launch_four<true, true>(p, stream) : launch_four<false, true>(p, stream);

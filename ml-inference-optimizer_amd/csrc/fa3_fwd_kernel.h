@@ -41,6 +41,7 @@ struct FaDev {
   int nqblk, xcd_remap;
   int qgrid;  // workgroups per (batch, head): nqblk, or ceil(nqblk/2) when causal blocks are paired (fa3_fwd2)
   float scale_log2e;  // softmax_scale * log2(e)
+  int o_blk;          // o is the [B*Sq, H*D] output in the blocked activation layout (mio_fa3_o_blocked_ok)
   int k_prescaled;    // K already carries softmax_scale * log2(e) (fa3_fwd4_kernel KPRE; mio_fa3_k_prescaled_ok)
 };
 

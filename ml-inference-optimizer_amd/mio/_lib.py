@@ -29,6 +29,7 @@ EXPORTS = (
     "mio_last_error",
     "mio_fa3_fwd",
     "mio_fa3_k_prescaled_ok",
+    "mio_fa3_o_blocked_ok",
     "mio_attn_merge",
     "mio_gemm_bias_act",
     "mio_fused_mlp_workspace_bytes",
@@ -79,6 +80,7 @@ class FaParams(C.Structure):
         ("k_offset", C.c_int32),
         ("softmax_scale", C.c_float),
         ("k_prescaled", C.c_int32),
+        ("o_blocked", C.c_int32),
     ]
 
 
@@ -99,6 +101,8 @@ def _load() -> C.CDLL:
     lib.mio_fa3_fwd.restype = i32
     lib.mio_fa3_k_prescaled_ok.argtypes = [C.POINTER(FaParams)]
     lib.mio_fa3_k_prescaled_ok.restype = i32
+    lib.mio_fa3_o_blocked_ok.argtypes = [C.POINTER(FaParams)]
+    lib.mio_fa3_o_blocked_ok.restype = i32
     lib.mio_attn_merge.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.mio_attn_merge.restype = i32
     lib.mio_gemm_bias_act.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i64, i32, i32, vp]

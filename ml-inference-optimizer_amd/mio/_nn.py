@@ -1,6 +1,7 @@
 """Small host-side helpers shared by the nn.Module wrappers (precision casting, Linear via the HIP GEMM)."""
 from __future__ import annotations
 
+import math
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -63,15 +64,15 @@ class CastCache:
 
 
 def linear(x: torch.Tensor, lin: nn.Linear, cache: CastCache, dtype: torch.dtype, activation: str = "none",
-           residual: Optional[torch.Tensor] = None, col_scale=None) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, col_scale=None, x_blocked_shape=None) -> torch.Tensor:
     """F.linear(x, W, b) (+ activation, + residual) on the MFMA GEMM.  At sizes that run the 256x256-tile kernels the
     weight is handed over in the blocked layout (repacked once per parameter version, cached next to the cast copy)."""
     w = cache.get(lin.weight, dtype)
     N, K = w.shape
-    M = x.numel() // K
+    M = x.numel() // K if x_blocked_shape is None else int(math.prod(x_blocked_shape[:-1]))
     wb = cache.get_blocked(lin.weight, dtype) if (K % 32 == 0 and ops.blocked_weight_ok(M, N, K, activation)) else None
     return ops.gemm_bias_act(x, w, cache.get(lin.bias, dtype), activation, residual=residual, w_blocked=wb,
-                             col_scale=col_scale)
+                             col_scale=col_scale, x_blocked_shape=x_blocked_shape)
 
 
 def prenorm_linear(x: torch.Tensor, ln: nn.LayerNorm, lin: nn.Linear, cache: CastCache, dtype: torch.dtype,

@@ -234,6 +234,13 @@ class FlashSelfAttention(_AttentionBase):
         if kpre:
             if self.training and cfg.dropout_p > 0.0:
                 raise NotImplementedError("attention dropout (training) is not supported by the inference kernel")
+            # where the output projection runs a 256-tile kernel the attention epilogue writes its [B*S, hidden] result in that
+            # GEMM's blocked activation layout (contiguous K-tiles on both operands)
+            if (self.hidden_size % 32 == 0 and ops.blocked_weight_ok(B * S, self.o_proj.out_features, self.hidden_size)
+                    and ops.fa3_o_blocked_ok(B, S, S, self.num_attention_heads, self.head_dim, n_tot, n_tot)):
+                ctx_b = ops.fa3_fwd(q, k, v, causal=cfg.causal, k_prescaled=True, out_blocked=True)
+                out = linear(ctx_b, self.o_proj, c, dt, residual=r, x_blocked_shape=(B, S, self.hidden_size))
+                return out if in_dtype == dt else out.to(in_dtype)
             ctx = ops.fa3_fwd(q, k, v, causal=cfg.causal, k_prescaled=True).view(B, S, self.hidden_size)
         else:
             ctx = self._attend(q, k, v, attention_mask).view(B, S, self.hidden_size)

@@ -111,6 +111,7 @@ def fa3_fwd(
     q_offset: int = 0,
     k_offset: int = 0,
     k_prescaled: bool = False,
+    out_blocked: bool = False,
 ):
     """One launch of the tiled attention kernel.
 
@@ -119,6 +120,9 @@ def fa3_fwd(
     Ring carry: o_acc fp32 [B,Sq,H,D] + lse fp32 [B,H,Sq]; carry_in continues from that state.
     k_prescaled: k already holds K * softmax_scale * log2(e), scaled in fp32 before its rounding to 16 bits
     (gemm_bias_act(col_scale=...)); only where fa3_k_prescaled_ok() says so -- ValueError otherwise.
+    out_blocked (k_prescaled launches, layout "bshd", where fa3_o_blocked_ok() says so): the output is returned as a
+    [ceil(B*Sq/256)*256, H*D] tensor in the blocked activation layout (include/mio_hip.h) for a following
+    gemm_bias_act(..., x_blocked_shape=(B, Sq, H*D)) -- the output projection then fetches contiguous K-tiles.
     Returns out (same layout as q) or (out, lse) if return_lse.
     """
     _need_cuda(q, k, v)
@@ -146,7 +150,11 @@ def fa3_fwd(
         raise ValueError("give either keep_mask or additive_mask, not both")
 
     p = _lib.FaParams()
-    if write_out:
+    if out_blocked:
+        if layout != "bshd" or not write_out or out is not None or not k_prescaled:
+            raise ValueError("out_blocked needs layout 'bshd', k_prescaled, write_out and no out= tensor")
+        out = torch.empty((B * Sq + 255) // 256 * 256, H * D, dtype=q.dtype, device=q.device)
+    elif write_out:
         if out is None:
             out = torch.empty_like(q, memory_format=torch.contiguous_format)
         elif out.shape != q.shape or out.dtype != q.dtype or out.stride(-1) != 1:
@@ -190,7 +198,7 @@ def fa3_fwd(
     _st(p.q_stride, q)
     _st(p.k_stride, k)
     _st(p.v_stride, v)
-    if out is not None:
+    if out is not None and not out_blocked:
         _st(p.o_stride, out)
     p.q, p.k, p.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
     p.o, p.lse, p.o_acc, p.mask = _ptr(out), _ptr(lse), _ptr(o_acc), _ptr(mask)
@@ -202,6 +210,11 @@ def fa3_fwd(
             raise ValueError("k_prescaled is only supported for head_dim <= 96 (<= 64 with the (o_acc, lse) carry), no mask, "
                              "Sq > 128")
         p.k_prescaled = 1
+    if out_blocked:
+        if not lib.mio_fa3_o_blocked_ok(C.byref(p)):
+            raise ValueError("out_blocked is only supported for k_prescaled launches without carry, head_dim <= 64, "
+                             "(H * D) % 32 == 0")
+        p.o_blocked = 1
     check(lib.mio_fa3_fwd(C.byref(p), _stream()))
     if return_lse:
         return out, lse
@@ -214,6 +227,12 @@ def fa3_k_prescaled_ok(B: int, Sq: int, Sk: int, H: int, D: int, k_row_stride: i
     (o_acc, lse) ring carry)."""
     return (D <= (64 if carry else 96) and Sq > 128 and Sk * k_row_stride * 2 < (1 << 32)
             and Sk * v_row_stride * 2 < (1 << 32))
+
+
+def fa3_o_blocked_ok(B: int, Sq: int, Sk: int, H: int, D: int, k_row_stride: int, v_row_stride: int) -> bool:
+    """True iff fa3_fwd(..., k_prescaled=True, out_blocked=True) is available for this geometry."""
+    return (not NO_BLOCKED_X and fa3_k_prescaled_ok(B, Sq, Sk, H, D, k_row_stride, v_row_stride) and D <= 64
+            and (H * D) % 32 == 0)
 
 
 def _canon_mask4(mask: torch.Tensor) -> torch.Tensor:

@@ -280,6 +280,37 @@ def test_fa3_carry_and_merge_roundtrip():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,S,H,Hkv,D,causal", [(2, 600, 4, 4, 64, True), (1, 1000, 6, 2, 32, False), (3, 300, 2, 2, 48, True)])
+def test_fa3_blocked_output(dtype, B, S, H, Hkv, D, causal):
+    """o_blocked: the same launch writes its [B*S, H*D] output in the GEMMs' blocked activation layout -- bit for bit the
+    row-major result after un-blocking, and the output projection fed with it equals the one fed with the row-major tensor."""
+    import math
+    ops = _ops()
+    torch.manual_seed(S + D)
+    q = torch.randn(B, S, H, D).to(dtype).to(DEV)
+    kt = (torch.randn(B, S, Hkv, D) * (math.log2(math.e) / math.sqrt(D))).to(dtype).to(DEV)
+    v = torch.randn(B, S, Hkv, D).to(dtype).to(DEV)
+    assert ops.fa3_o_blocked_ok(B, S, S, H, D, Hkv * D, Hkv * D)
+    o = ops.fa3_fwd(q, kt, v, causal=causal, k_prescaled=True)
+    ob = ops.fa3_fwd(q, kt, v, causal=causal, k_prescaled=True, out_blocked=True)
+    M, N = B * S, H * D
+    Mp = (M + 255) // 256 * 256
+    assert tuple(ob.shape) == (Mp, N)
+    un = ob.view(Mp // 256, N // 32, 256, 32).permute(0, 2, 1, 3).reshape(Mp, N)[:M]
+    assert torch.equal(un, o.view(M, N))
+    with pytest.raises(ValueError):  # needs a k_prescaled launch
+        ops.fa3_fwd(q, kt, v, causal=causal, out_blocked=True)
+    if N % 128 == 0 and ops.blocked_weight_ok(M, 256, N):
+        w = (torch.randn(256, N) * 0.05).to(dtype).to(DEV)
+        bias = torch.randn(256).to(dtype).to(DEV)
+        res = torch.randn(B, S, 256).to(dtype).to(DEV)
+        wb = ops.block_weight(w)
+        y0 = ops.gemm_bias_act(o.view(B, S, N), w, bias, residual=res, w_blocked=wb)
+        y1 = ops.gemm_bias_act(ob, w, bias, residual=res, w_blocked=wb, x_blocked_shape=(B, S, N))
+        assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,S,H,Hkv,D,causal", [(1, 640, 4, 4, 64, False), (2, 450, 4, 2, 64, True), (1, 832, 3, 3, 48, True)])
 def test_fa3_k_prescaled_carry(dtype, B, S, H, Hkv, D, causal):
     """The ring form of the k_prescaled launch (fa3_fwd5_kernel CARRY): K~ / V shards visited in ring order -- the local

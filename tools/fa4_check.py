@@ -96,20 +96,24 @@ def run(n, causal):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(n):
-        if KP:
+        if KP and BLK:
+            ops.fa3_fwd(q, kpre, v, causal=causal, k_prescaled=True, out_blocked=True)
+        elif KP:
             ops.fa3_fwd(q, kpre, v, causal=causal, out=o, k_prescaled=True)
         else:
             ops.fa3_fwd(q, k, v, causal=causal, out=o)
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 VAR = int(os.environ.get("FA4_VAR", "0"))  # fwd4 variant (mio_dbg_set(0, VAR)); e.g. 64 = row sums on the vector ALU
+BLK = False
 def sel(impl):
-    global KP
+    global KP, BLK
     KP = (impl >= 6)
-    _lib.lib.mio_dbg_set(1, 5 if impl == 8 else (4 if impl in (4, 5, 6) else 3))
+    BLK = (impl == 9)  # fwd5 writing the blocked activation layout
+    _lib.lib.mio_dbg_set(1, 5 if impl >= 8 else (4 if impl in (4, 5, 6) else 3))
     _lib.lib.mio_dbg_set(0, VAR if impl == 5 else 0)
 for causal in (True, False):
-    impls = (3, 4, 5, 6, 7, 8) if (VAR and causal) else (3, 4, 6, 7, 8)
+    impls = (3, 4, 5, 6, 7, 8, 9) if (VAR and causal) else (3, 4, 6, 7, 8, 9)
     res = {i: [] for i in impls}
     for impl in impls:
         sel(impl); run(200, causal)
@@ -119,7 +123,7 @@ for causal in (True, False):
     fl = (2.0 * B * S * (S + 1) * H * D) if causal else 4.0 * B * S * S * H * D
     for impl in impls:
         t = min(res[impl])
-        print(f"causal={int(causal)} fwd{impl if impl < 5 else ('4/var' + str(VAR) if impl == 5 else ('4/k_prescaled' if impl == 6 else ('3/k_prescaled' if impl == 7 else '5/k_prescaled (16x16x32)')))}: min {t:.4f} ms  {fl / t / 1e9:.0f} TFLOP/s  frac {fl / t / 1e9 / 2500:.3f}", flush=True)
+        print(f"causal={int(causal)} fwd{impl if impl < 5 else ('4/var' + str(VAR) if impl == 5 else ('4/k_prescaled' if impl == 6 else ('3/k_prescaled' if impl == 7 else ('5/k_prescaled (16x16x32)' if impl == 8 else '5/k_prescaled, blocked output'))))}: min {t:.4f} ms  {fl / t / 1e9:.0f} TFLOP/s  frac {fl / t / 1e9 / 2500:.3f}", flush=True)
 if VAR:  # the variant's values (causal bf16 only is instantiated)
     _lib.lib.mio_dbg_set(1, 4); _lib.lib.mio_dbg_set(0, VAR)
     o5, l5 = ops.fa3_fwd(q, k, v, causal=True, return_lse=True)
