@@ -505,6 +505,34 @@ def test_gemm_big_tiles_exact():
     assert bool((out[M:, :] == 7).all()) and bool((out[:, N:] == 7).all())
 
 
+@pytest.mark.parametrize("N,residual", [(1024 + 16, True), (3072, False)])
+def test_gemm_exact_k4096(N, residual):
+    """The integer case at K = 4096 (the fc2 depth): x, w in {-1, 0, 1}, dot products up to 4096 in magnitude are exact in the
+    fp32 accumulators, so the 16-bit result must equal the exactly rounded integer sum (+ integer residual) bit for bit -- on
+    the plain operands, with the blocked weight, and with both operands blocked (residual: one-tile kernel, else persistent)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    M, K = 2048 + 250, 4096
+    x = torch.randint(-1, 2, (M, K), generator=g).to(torch.bfloat16)
+    w = torch.randint(-1, 2, (N, K), generator=g).to(torch.bfloat16)
+    r = torch.randint(-8, 9, (M, N), generator=g).to(torch.bfloat16) if residual else None
+    ref = x.double() @ w.double().T
+    if r is not None:
+        ref = ref + r.double()
+    want = ref.to(torch.bfloat16)  # round-to-nearest-even of the exact integer
+    xd, wd = x.to(DEV), w.to(DEV)
+    rd = None if r is None else r.to(DEV)
+    y0 = ops.gemm_bias_act(xd, wd, None, residual=rd)
+    assert torch.equal(y0.cpu(), want)
+    if ops.blocked_weight_ok(M, N, K):
+        wb = ops.block_weight(wd)
+        y1 = ops.gemm_bias_act(xd, wd, None, residual=rd, w_blocked=wb)
+        assert torch.equal(y1.cpu(), want)
+        xb = ops.block_weight(xd)  # the blocked activation layout is the weight layout with m in the place of n
+        y2 = ops.gemm_bias_act(xb, wd, None, residual=rd, w_blocked=wb, x_blocked_shape=(M, K))
+        assert torch.equal(y2.cpu(), want)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_layernorm_blocked_handover(dtype):
     """LayerNorm -> GEMM hand-over in the blocked activation layout: layout exactness of mio_layernorm_fwd_bx against
