@@ -94,7 +94,6 @@ static int fused_mlp_impl(const void* x, const void* w1, const void* b1, const v
     p.x_blk = xblk; p.y_blk = 1; p.w_blk = wblk;
     p.dbg = nullptr;
     p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f;
-  p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f;
     int rc = gemm_dispatch(p, act, dtype, (hipStream_t)stream);
     if (rc != 0) return rc;
     p.x = workspace; p.w = w2; p.bias = b2; p.res = residual; p.y = y;

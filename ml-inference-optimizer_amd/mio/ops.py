@@ -364,6 +364,12 @@ def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_g
     _vec_ok(bias, N, x.dtype, "bias")
     if act == _lib.ACT_SWIGLU:
         _vec_ok(bias_gate, N, x.dtype, "bias_gate")
+    if w_blocked is not None:
+        # the blocked copy travels as a raw pointer: a stale repack (other dtype / device / shape) must not get that far
+        if w_blocked.dtype != x.dtype or w_blocked.device != x.device:
+            raise ValueError("w_blocked must have x's dtype and device (repack after converting the module)")
+        if w_blocked.numel() != (N + 255) // 256 * 256 * K or not w_blocked.is_contiguous():
+            raise ValueError(f"w_blocked has {w_blocked.numel()} elements, expected ceil(N/256)*256*K = {(N + 255) // 256 * 256 * K}")
     if col_scale is not None:
         lo, hi, val = int(col_scale[0]), int(col_scale[1]), float(col_scale[2])
         Mcs = int(math.prod(x_blocked_shape[:-1])) if x_blocked_shape is not None else x.numel() // K

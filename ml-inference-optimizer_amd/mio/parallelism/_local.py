@@ -12,17 +12,19 @@ from .. import ops
 
 import weakref
 
-_blocked = {}  # id(weight tensor) -> (weakref to it, version, blocked copy): the 256x256-tile GEMMs take blocked weights
+_blocked = {}  # id(weight tensor) -> (weakref to it, key, blocked copy): the 256x256-tile GEMMs take blocked weights
 
 
 def _blocked_weight(w):
+    # keyed like CastCache.get_blocked: module.half() / .to(device) / `param.data = loaded` keep id() and _version
+    key = (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape))
     hit = _blocked.get(id(w))
-    if hit is not None and hit[0]() is w and hit[1] == w._version:
+    if hit is not None and hit[0]() is w and hit[1] == key:
         return hit[2]
     if len(_blocked) > 256:
         _blocked.clear()
     wb = ops.block_weight(w.detach())
-    _blocked[id(w)] = (weakref.ref(w), w._version, wb)
+    _blocked[id(w)] = (weakref.ref(w), key, wb)
     return wb
 
 

@@ -261,7 +261,7 @@ class SequenceParallelAttention(nn.Module):
         q = _local.linear(hidden_states, self.query.weight, self.query.bias).view(B, Sl, H, D)
         # ring mode: the K projection scales its columns by softmax_scale * log2(e) in fp32 before their one rounding, and
         # every ring step's attention launch drops its per-score multiply (ops.fa3_fwd k_prescaled) -- where both ends can
-        kpre = (mode == "ring" and cfg.sp_size > 1 and attention_mask is None
+        kpre = (mode == "ring" and cfg.sp_size > 1 and attention_mask is None and (H * D) % 128 == 0
                 and _local.k_prescale_ok(B, Sl // (2 if cfg.zigzag else 1), H, D, B * Sl, H * D, hidden_states.shape[-1]))
         kcs = (0, H * D, D ** -0.5 * 1.4426950408889634) if kpre else None
         k = _local.linear(hidden_states, self.key.weight, self.key.bias, col_scale=kcs).view(B, Sl, H, D)

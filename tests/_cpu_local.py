@@ -17,6 +17,8 @@ def linear(x, weight, bias=None, activation="none", residual=None, out=None, col
     y = _ACTS[activation](y)
     if col_scale is not None:  # (lo, hi, value): scaled before the one rounding to the storage dtype
         lo, hi, val = col_scale
+        if lo % 128 or hi % 128:  # ops.gemm_bias_act / mio_gemm_bias_act_bw_cs refuse such a range
+            raise ValueError(f"col_scale range [{lo}, {hi}) must be multiples of 128")
         y[..., lo:hi] = y[..., lo:hi] * val
     if residual is not None:
         y = y + residual.double()

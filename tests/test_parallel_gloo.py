@@ -192,6 +192,23 @@ def _w_sp_modules(rank, world):
         assert y.shape == x.shape and (y - ref).abs().max() < 1e-4, (mode, causal, zz)
 
 
+def _w_sp_ring_hidden_1600(rank, world):
+    """H * D = 1600 (GPT-2-XL: 25 heads of 64) is not a multiple of 128: the ring branch must not ask the K projection for
+    a column scale (the checker's linear refuses such a range exactly as ops.gemm_bias_act does), ADVICE r2."""
+    import oracle
+    from mio.parallelism import SequenceParallelConfig, SequenceParallelAttention, SequenceShardedModule
+    torch.manual_seed(5)
+    d, H, B, S = 1600, 25, 1, 4 * world
+    x = torch.randn(B, S, d) * 0.3
+    cfg = SequenceParallelConfig(world_size=world, sp_size=world, attention_handling="ring", exchange="ring")
+    att = SequenceParallelAttention(d, H, cfg, attention_dropout=0.0)
+    y = SequenceShardedModule(att, cfg)(x)
+    F = torch.nn.functional
+    q, k, v = (F.linear(x, l.weight, l.bias).view(B, S, H, d // H) for l in (att.query, att.key, att.value))
+    ref = F.linear(oracle.standard_attention(q, k, v).reshape(B, S, d).float(), att.output.weight, att.output.bias)
+    assert (y - ref).abs().max() < 1e-4
+
+
 # ---------------------------------------------------------------- tests
 def _w_tp_x_sp(rank, world):
     """tensor (2) x sequence (2) mesh: heads split over the tensor group, the sequence over the sequence group; the
@@ -297,6 +314,10 @@ def test_ring_attention_additive_mask_ws2():
 
 def test_sequence_parallel_modules_ws2():
     _run("_w_sp_modules", 2)
+
+
+def test_sequence_parallel_ring_hidden_not_multiple_of_128_ws2():
+    _run("_w_sp_ring_hidden_1600", 2)
 
 
 def test_tensor_x_sequence_groups_ws4():
