@@ -1,0 +1,340 @@
+// 256x256 bf16/fp16 GEMM on v_mfma_f32_16x16x32 with EIGHT waves per workgroup: two waves on every SIMD, run as a
+// ping-pong -- while one wave of a SIMD issues its MFMAs the other reads its next fragments from LDS and requests the
+// K-tile three ahead (cdna_hip_programming.md, "The 256^2 8-phase template"; MI355X_MICROARCH.md, "Two waves per SIMD").
+// Persistent: a workgroup walks its output tiles, the load stream runs on across tiles, the output leaves as a burst of
+// 16-byte stores that the next tile's first K-tiles cover.
+//
+// Why (round-3 measurements, tools/gemm8_ksweep.py, M 32768 x N 3072, blocked operands): the one-wave-per-SIMD kernels pay
+// issue time for everything that is not an MFMA.  Per K-tile of 32 and workgroup, zero operands (clock 2.39 GHz) / random:
+//   gemm4w16_kernel  555 / 696 ns     gemm4w16p_kernel (stores trickled through the K loop)  618 / 750 ns
+//   this loop        520 / 678 ns     (1024 matrix-pipe cycles = 428 ns)
+// and timing-only ablations of this loop: without its LDS-DMA requests 436 ns, without its fragment reads unchanged, with
+// every request re-reading L1-resident bytes 444 ns, without the counted wait unchanged: what is left between the loop and
+// the matrix pipe is the L2 -> CU fetch rate (32 KiB per K-tile), not instruction issue and not latency; blocked (contiguous
+// 1-KiB) pieces are fetched 17 % faster than 64-byte row pieces.  Per tile the one-tile kernels lose another 5.6 - 7.6 us
+// (workgroup launch, first tiles' latency, read-out, store drain): at K = 1024 that is 25 % of the time, hence persistent.
+//
+// Structure (operand formats are gemm4w16_kernel's: K-tile = 32, four 32-KiB LDS stages X[256][32] + W[256][32], 64-byte
+// rows with the g6_swz chunk swizzle on the DMA source address, blocked or row-major operands):
+//   * wave w: group = w >> 2 (waves w and w + 4 share a SIMD), column quarter = w & 3; wave tile = 128 rows (the
+//     group's half of the tile) x 64 columns = 8 x 4 accumulator tiles of 16x16 (128 registers).  Weight tile = MFMA A
+//     operand, activation tile = B operand: a lane holds ONE output row and 4 consecutive columns (lane-local epilogue).
+//   * a K-tile is two SEGMENTS per wave, separated by s_barrier: [12 fragment reads + 4 DMA pieces of the K-tile three
+//     ahead + counted wait] | [32 MFMAs].  Group 1 runs one barrier behind group 0 (one extra s_barrier in front of its
+//     loop, one behind group 0's), so at any time one wave of a SIMD is in its MFMA segment and the other in its read
+//     segment.  (Two phases of 16 MFMAs per K-tile, the guide's template granularity, measured 2.5 % slower.)
+//   * hazards, counted in a wave's own segments (group 1's segment s runs during group 0's segment s + 1):
+//       RAW  a K-tile's pieces are waited for (counted vmcnt, own pieces) in a read segment L and first read in read
+//            segment L + 2: every wave of both groups has passed its wait and a barrier behind it by then;
+//       WAR  a read segment ends with lgkmcnt(0) IN FRONT of its barrier, so a stage is restaged from the second
+//            segment after its last read (the K-tile three ahead reuses the stage of the K-tile before this one).
+//     Three K-tiles stay in flight (vmcnt(8) = the two youngest K-tiles of 4 pieces per wave).
+//   * tile boundary: the last three K-tiles of a tile request K-tiles 0..2 of the workgroup's next tile (the stage index
+//     runs on); the last read segment waits vmcnt(4) (next K-tiles 0 AND 1 landed), so the next tile's first read segment
+//     needs no wait; its second one waits vmcnt(8) as usual, which by then covers the 16 output stores issued in
+//     between (stores and loads retire out of order with each other: only "at most 8 operations of any kind in flight"
+//     says that K-tile 2 has landed).  The first K-tile of a tile multiplies with C = 0: no zeroing pass.
+//   * GLU (SwiGLU, reference kernels/triton/mlp_kernels.py:417-641): the weight tile interleaves 32 gate rows and 32 up
+//     rows per wave (mio_weight_block_glu), so accumulator columns 0..31 / 32..63 of a wave are gate / up of the SAME 32
+//     output columns and silu(gate) * up is lane-local; the output tile is 256 x 128.
+#pragma once
+#include <type_traits>
+
+#include "gemm4w16_kernel.h"
+
+constexpr int G8_THREADS = 512;
+constexpr int G8_BIAS_OFF = G6_SMEM;  // 8 waves x 256 B: each wave's slice of the bias row(s)
+constexpr int G8_SMEM = G6_SMEM + 8 * 256;
+
+// VAR (timing-only ablations, diagnostic library): 4 = no prefetch issue in the loop, 16 = no counted wait,
+// 64 = every piece re-reads K-tile 0, 128 = in-kernel stamps (tools/gemm8_stamps.py)
+template <typename T, int ACT, bool RES, int VAR = 0>
+__global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
+  using X8 = typename DT<T>::x8;
+  using X4 = typename DT<T>::x4;
+  constexpr bool GLU = (ACT == MIO_ACT_SWIGLU);
+  constexpr bool SAFE_ACT = true;  // scalar activation math (gemm_kernel.h gemm_act2)
+  constexpr int BN = GLU ? 128 : 256;  // output columns per tile
+  constexpr int WN = BN / 4;           // output columns per wave
+  constexpr int ONT = WN / 16;         // output column tiles per wave
+  static_assert(!(GLU && RES), "no residual on the gated stage");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int nk = p.K / G6_BK;
+  const int ntiles = p.tiles_m * p.tiles_n;
+
+  // ---- operand addressing of the tile being computed / prefetched (gemm4w16p_kernel's, 2 + 2 pieces per wave)
+  int xvo[2], wvo[2];
+  __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t wrs = xrs;
+  int64_t m0 = 0, mrem = 0;
+  int n0 = 0, nrem = 0;  // in OUTPUT columns
+  // lane id recomputed from an opaque instruction wherever lane-constant addresses are built inside the tile loop: hoisted
+  // out of it (LICM) they are kept live -- 32 VGPRs of store offsets alone -- and spilled (gemm4w16p_kernel.h)
+  auto lane_now = [&]() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
+  auto setup = [&](int tile) {
+    int tm, tn;
+    gemm_tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
+    m0 = (int64_t)tm * 256;
+    n0 = tn * BN;
+    mrem = p.M - m0;
+    nrem = p.N - n0;
+    const int ln = lane_now(), prow = ln >> 2, pcs = ln & 3;
+    const int wrows = GLU ? 256 : nrem;  // GLU weights are blocked and padded: every row of the tile exists
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (wave * 2 + i) * 16 + prow;  // 0..255
+      const int kch = pcs ^ g6_swz(row);
+      const int xr = (row < mrem) ? row : (int)(mrem - 1);
+      const int wrw = (row < wrows) ? row : (wrows - 1);
+      xvo[i] = (p.x_blk ? xr * 64 : xr * (int)p.ldx * 2) + 16 * kch;
+      wvo[i] = (p.w_blk ? wrw * 64 : wrw * (int)p.ldw * 2) + 16 * kch;
+    }
+    xrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.x_blk ? (void*)((const char*)p.x + ((int64_t)tm * nk << 14)) : (void*)((const T*)p.x + m0 * p.ldx), 0, 0x7fffffff,
+        0x00020000);
+    wrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.w_blk ? (void*)((const char*)p.w + ((int64_t)tn * nk << 14)) : (void*)((const T*)p.w + (int64_t)n0 * p.ldw), 0,
+        0x7fffffff, 0x00020000);
+  };
+  const int xkstep = p.x_blk ? 16384 : G6_BK * 2;
+  const int wkstep = p.w_blk ? 16384 : G6_BK * 2;
+
+#define IC(N) std::integral_constant<int, N>{}
+  int sbase = 0;  // LDS stage of the current tile's K-tile 0 (the stage index runs on across tiles)
+  // piece i (0 / 1) of X (which = 0) or W (which = 1): K-tile `kl` of the tile `setup` describes into stage (sbase + ks) & 3
+  auto issue_one = [&](int ks, int kl, auto I, auto WHICH) {
+    constexpr int i = decltype(I)::value, which = decltype(WHICH)::value;
+    char* dst = smem + ((sbase + ks) & (G6_STAGES - 1)) * G6_BUF + which * G6_XT + (wave * 2 + i) * 1024;
+    int koff = kl * (which ? wkstep : xkstep);
+    if constexpr ((VAR & 64) != 0) koff = 0;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? wrs : xrs, (MIO_LDS void*)dst, 16, which ? wvo[i] : xvo[i], koff, 0, 0);
+  };
+  auto issue_tile = [&](int ks, int kl) {
+    issue_one(ks, kl, IC(0), IC(0));
+    issue_one(ks, kl, IC(0), IC(1));
+    issue_one(ks, kl, IC(1), IC(0));
+    issue_one(ks, kl, IC(1), IC(1));
+  };
+
+  const int co = (g ^ g6_swz(c16)) * 16;
+  const int xbase = (grp * 128 + c16) * 64 + co;
+  const int wbase = G6_XT + (wn * 64 + c16) * 64 + co;
+
+  X8 fx[8];
+  X8 fw[4];
+  f32x4_t acc[8][4];
+
+  // one K-tile: kt = index inside the current tile (stage (sbase + kt) & 3), kl = the K-tile requested three ahead (of the
+  // tile `setup` describes), WAIT = the counted wait of the read segment (8: the next K-tile has landed; 4: the next two)
+  auto ktile = [&](int kt, int kl, auto FIRST, auto WAIT) {
+    const char* buf = smem + ((sbase + kt) & (G6_STAGES - 1)) * G6_BUF;
+    // -- read segment
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) fw[nt] = __builtin_bit_cast(X8, *(const u32x4_t*)(buf + wbase + nt * 1024));
+#pragma unroll
+    for (int t = 0; t < 8; ++t) fx[t] = __builtin_bit_cast(X8, *(const u32x4_t*)(buf + xbase + t * 1024));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr ((VAR & 4) == 0) issue_tile(kt + 3, kl);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr ((VAR & 16) == 0 && decltype(WAIT)::value == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr ((VAR & 16) == 0 && decltype(WAIT)::value == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read has returned before the barrier (WAR rule above)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // -- MFMA segment
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if constexpr (decltype(FIRST)::value != 0)
+          acc[t][nt] = DT<T>::mfma16(fw[nt], fx[t], (f32x4_t){0.f, 0.f, 0.f, 0.f});
+        else
+          acc[t][nt] = DT<T>::mfma16(fw[nt], fx[t], acc[t][nt]);
+      }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  int tile = blockIdx.x;  // the launcher keeps gridDim.x <= ntiles
+  setup(tile);
+  issue_tile(0, 0);
+  issue_tile(1, 1);
+  issue_tile(2, 2);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K-tiles 0 and 1 landed for this wave
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one segment behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (;;) {
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, sr0 = 0;
+    if constexpr ((VAR & 128) != 0) {
+      st[0] = __builtin_amdgcn_s_memtime();
+      sr0 = __builtin_amdgcn_s_memrealtime();
+    }
+    // K-tiles 0 .. nk-4 prefetch inside this tile (nk >= 4)
+    ktile(0, 3, IC(1), IC(0));
+    if constexpr ((VAR & 128) != 0) st[1] = __builtin_amdgcn_s_memtime();
+    for (int kt = 1; kt < nk - 3; ++kt) {
+      ktile(kt, kt + 3, IC(0), IC(8));
+      if constexpr ((VAR & 128) != 0) {
+        if (kt == 1) st[2] = __builtin_amdgcn_s_memtime();
+      }
+    }
+    if constexpr ((VAR & 128) != 0) st[3] = __builtin_amdgcn_s_memtime();
+
+    // ---- this wave's output coordinates; from here on `setup` describes the next tile
+    const int64_t om0 = m0 + grp * 128;
+    const int on0 = n0 + wn * WN;
+    const int64_t omrem = mrem - grp * 128;  // rows of the wave tile inside M (may be <= 0)
+    const int onrem = nrem - wn * WN;
+    // bias: each wave DMAs the slice of the bias row(s) under its own columns into its private LDS slot and reads it back
+    // in the read-out (held in registers across the tail K-tiles hipcc would drain the prefetch in front of the first use).
+    // Slot dwords 0..31 = the wave's 64 accumulator columns; GLU: 0..15 gate bias (bias_g), 16..31 up bias (bias) of the
+    // wave's 32 output columns.  The request is older than the 12 loads the tail issues: their counted waits cover it.
+    const bool have_bias = GLU ? (p.bias != nullptr || p.bias_g != nullptr) : (p.bias != nullptr);
+    if (have_bias) {
+      const int l = lane_now() & 31, lg = GLU ? (l & 15) : l;
+      const int n = on0 + 2 * lg;
+      const int nc = n < p.N - 2 ? n : p.N - 2;  // columns past N are never stored
+      const T* base = (const T*)p.bias;
+      if constexpr (GLU) {
+        base = (l < 16) ? (const T*)p.bias_g : (const T*)p.bias;
+        if (base == nullptr) base = (const T*)(p.bias ? p.bias : p.bias_g);  // (that half is ignored by the read-out)
+      }
+      const T* src = base + nc;
+      const uint32_t lds = (uint32_t)(size_t)((MIO_LDS char*)(smem + G8_BIAS_OFF + wave * 256));
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(lds), "v"(src) : "memory", "m0");
+    }
+    const int next = tile + (int)gridDim.x;
+    const bool has_next = next < ntiles;
+    if (has_next) setup(next);  // (no next tile: K-tiles 0..2 of this one are fetched again into idle stages, never read)
+    __builtin_amdgcn_sched_barrier(0);
+    ktile(nk - 3, 0, IC(0), IC(8));
+    ktile(nk - 2, 1, IC(0), IC(8));
+    ktile(nk - 1, 2, IC(0), IC(4));
+    sbase = (sbase + nk) & (G6_STAGES - 1);
+    if constexpr ((VAR & 128) != 0) st[4] = __builtin_amdgcn_s_memtime();
+
+    // ---- read-out: bias / activation / column scale / residual, row-pair exchange, 16-byte stores.
+    // Stores and residual loads are buffer instructions on a per-tile descriptor (base = the wave tile's first element):
+    // a 32-bit lane offset fixed per tile, the row-pair step in the scalar offset, the column tile in the immediate, and
+    // rows / columns past M / N get an out-of-range offset that the range check drops -- no branches, no 64-bit math.
+    {
+      const int ln = lane_now(), c16 = ln & 15, g = ln >> 4;  // (shadows the kernel-scope values on purpose)
+      u32x2_t bq[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bq[nt] = (u32x2_t){0u, 0u};
+      if (have_bias) {
+        const char* bl = smem + G8_BIAS_OFF + wave * 256 + 8 * g;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bq[nt] = *(const u32x2_t*)(bl + nt * 32);
+        if constexpr (GLU) {
+          if (p.bias_g == nullptr) bq[0] = bq[1] = (u32x2_t){0u, 0u};
+          if (p.bias == nullptr) bq[2] = bq[3] = (u32x2_t){0u, 0u};
+        }
+      }
+      const int ncs = on0 & ~127;  // column scale: a wave's columns lie inside one 128-column unit
+      const float csv = (ncs >= p.cs_lo && ncs < p.cs_hi) ? p.cs_val : 1.0f;
+      const f32x2_t cs2 = {csv, csv};
+      const bool full = (omrem >= 128) && (onrem >= WN);  // wave-uniform
+      const int rS = c16 + 16 * (g & 1);  // the row (inside a row pair) this lane stores after the exchange
+      // output: y_blk = blocked activation layout of the consuming GEMM ((256-row, 32-column) blocks of 16 KiB)
+      const int64_t yb = p.y_blk ? ((((om0 >> 8) * (int64_t)(p.N >> 5) + (on0 >> 5)) << 14) + (om0 & 255) * 64) : (om0 * p.ldy + on0) * 2;
+      const uint32_t ylo = __builtin_amdgcn_readfirstlane((uint32_t)yb), yhi = __builtin_amdgcn_readfirstlane((uint32_t)(yb >> 32));
+      const __amdgpu_buffer_rsrc_t yrs =
+          __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.y + (((uint64_t)yhi << 32) | ylo)), 0, 0x7fffffff, 0x00020000);
+      const int yvo = p.y_blk ? rS * 64 + 16 * (g >> 1) : (rS * (int)p.ldy + 8 * (g >> 1)) * 2;
+      const int ystep = p.y_blk ? 32 * 64 : 64 * (int)p.ldy;  // bytes per row pair (32 rows)
+      __amdgpu_buffer_rsrc_t rrs = yrs;
+      int rvo = 0, rstep = 0;
+      if constexpr (RES) {
+        // (a wave tile that lies completely past M or N stores nothing: its loads read the matrix' first rows / columns)
+        const int64_t rb = ((omrem > 0 ? om0 : 0) * p.ldr + (onrem > 0 ? on0 : 0)) * 2;
+        const uint32_t rlo = __builtin_amdgcn_readfirstlane((uint32_t)rb), rhi = __builtin_amdgcn_readfirstlane((uint32_t)(rb >> 32));
+        rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.res + (((uint64_t)rhi << 32) | rlo)), 0, 0x7fffffff, 0x00020000);
+        rvo = (c16 * (int)p.ldr + 4 * g) * 2;  // accumulator layout: row c16 (+16 for the pair's second tile), columns 4 g ..
+        rstep = 64 * (int)p.ldr;
+      }
+#pragma unroll
+      for (int mtp = 0; mtp < 4; ++mtp) {
+        u32x2_t resA[ONT], resB[ONT];
+        if constexpr (RES) {
+          // rows past M: clamped to the tile's first row (their results are never stored)
+          const int oa = (full || mtp * 32 + c16 < omrem) ? rvo + mtp * rstep : rvo - c16 * (int)p.ldr * 2;
+          const int ob = (full || mtp * 32 + 16 + c16 < omrem) ? rvo + mtp * rstep + (rstep >> 1) : rvo - c16 * (int)p.ldr * 2;
+#pragma unroll
+          for (int nt = 0; nt < ONT; ++nt) {
+            const int cofs = (full || nt * 16 + 4 * g < onrem) ? nt * 32 : -8 * g;
+            resA[nt] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rrs, oa + cofs, 0, 0));
+            resB[nt] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rrs, ob + cofs, 0, 0));
+          }
+        }
+        const bool mok = full || (mtp * 32 + rS < omrem);
+#pragma unroll
+        for (int nt = 0; nt < ONT; ++nt) {
+          const f32x4_t a = acc[2 * mtp][nt], b = acc[2 * mtp + 1][nt];
+          const X4 bv = __builtin_bit_cast(X4, bq[nt]);
+          const f32x2_t b01 = {(float)bv[0], (float)bv[1]}, b23 = {(float)bv[2], (float)bv[3]};
+          f32x2_t a01, a23, c01, c23;
+          if constexpr (GLU) {
+            const f32x4_t au = acc[2 * mtp][nt + 2], bu = acc[2 * mtp + 1][nt + 2];
+            const X4 uv = __builtin_bit_cast(X4, bq[nt + 2]);
+            const f32x2_t u01 = {(float)uv[0], (float)uv[1]}, u23 = {(float)uv[2], (float)uv[3]};
+            a01 = gemm_act2<MIO_ACT_SILU, SAFE_ACT>((f32x2_t){a[0], a[1]} + b01) * ((f32x2_t){au[0], au[1]} + u01);
+            a23 = gemm_act2<MIO_ACT_SILU, SAFE_ACT>((f32x2_t){a[2], a[3]} + b23) * ((f32x2_t){au[2], au[3]} + u23);
+            c01 = gemm_act2<MIO_ACT_SILU, SAFE_ACT>((f32x2_t){b[0], b[1]} + b01) * ((f32x2_t){bu[0], bu[1]} + u01);
+            c23 = gemm_act2<MIO_ACT_SILU, SAFE_ACT>((f32x2_t){b[2], b[3]} + b23) * ((f32x2_t){bu[2], bu[3]} + u23);
+          } else {
+            a01 = gemm_act2<ACT, SAFE_ACT>((f32x2_t){a[0], a[1]} + b01) * cs2;
+            a23 = gemm_act2<ACT, SAFE_ACT>((f32x2_t){a[2], a[3]} + b23) * cs2;
+            c01 = gemm_act2<ACT, SAFE_ACT>((f32x2_t){b[0], b[1]} + b01) * cs2;
+            c23 = gemm_act2<ACT, SAFE_ACT>((f32x2_t){b[2], b[3]} + b23) * cs2;
+          }
+          if constexpr (RES) {
+            const X4 ra = __builtin_bit_cast(X4, resA[nt]), rb = __builtin_bit_cast(X4, resB[nt]);
+            a01 += (f32x2_t){(float)ra[0], (float)ra[1]};
+            a23 += (f32x2_t){(float)ra[2], (float)ra[3]};
+            c01 += (f32x2_t){(float)rb[0], (float)rb[1]};
+            c23 += (f32x2_t){(float)rb[2], (float)rb[3]};
+          }
+          uint32_t pa01 = pack2<T>(a01[0], a01[1]), pc01 = pack2<T>(c01[0], c01[1]), pa23 = pack2<T>(a23[0], a23[1]), pc23 = pack2<T>(c23[0], c23[1]);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(pa01, pc01, false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(pa23, pc23, false, false);
+          const u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
+          const bool ok = mok && (full || nt * 16 + 8 * (g >> 1) < onrem);
+          const int off = ok ? yvo : 0x7fffffff;  // out of range: dropped by the buffer range check
+          // column tile nt: +32 bytes in a row; blocked: tiles 2, 3 lie in the next 32-column block (16 KiB further)
+          __builtin_amdgcn_raw_buffer_store_b128(o, yrs, off, mtp * ystep + (p.y_blk ? ((nt >> 1) << 14) + ((nt & 1) << 5) : nt * 32), 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr ((VAR & 128) != 0) {  // per (tile, wave): start, K-tile 0 / 1 done, tail start, loop end, read-out end; 100 MHz
+      st[5] = __builtin_amdgcn_s_memtime();
+      const unsigned long long sr1 = __builtin_amdgcn_s_memrealtime();
+      if (lane_now() == 0 && p.dbg != nullptr) {
+        unsigned long long* d = p.dbg + ((size_t)tile * 8 + wave) * 8;
+        d[0] = st[0]; d[1] = st[1]; d[2] = st[2]; d[3] = st[3]; d[4] = st[4]; d[5] = st[5]; d[6] = sr0; d[7] = sr1;
+      }
+    }
+    if (!has_next) break;
+    tile = next;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef IC
+}

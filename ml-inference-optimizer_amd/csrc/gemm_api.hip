@@ -11,6 +11,7 @@ extern template int gemm_launch<_Float16>(GemmDev, int, hipStream_t);
 // library always takes the default dispatch (0) and reads no environment variable.
 int mio_gemm_impl() {
 #ifdef MIO_DIAG
+  if (mio_dbg_get(4) != 0) return mio_dbg_get(4);  // run-time override for same-process A/B (tools/gemm8_ab.py)
   static const int v = [] {
     const char* e = std::getenv("MIO_GEMM_IMPL");
     if (e == nullptr) return 0;
@@ -18,6 +19,7 @@ int mio_gemm_impl() {
     if (s == "v1") return 1;
     if (s == "4wp") return 5;
     if (s == "4w16") return 6;
+    if (s == "8w1") return 9;   // gemm8w_kernel, one workgroup per tile
     return 0;
   }();
   return v;
@@ -63,7 +65,7 @@ extern "C" int mio_gemm_bias_act(const void* x, const void* w, const void* bias,
 // then the intermediate can use the blocked layout (GemmDev::x_blk / y_blk).
 static bool mlp_blocked_ok(int64_t M, int32_t d, int32_t I, int32_t act, bool residual) {
   (void)residual;
-  if (act == MIO_ACT_SWIGLU || (mio_gemm_impl() != 0 && mio_gemm_impl() != 5)) return false;
+  if (act == MIO_ACT_SWIGLU || (mio_gemm_impl() != 0 && mio_gemm_impl() < 5)) return false;
   const int64_t tm = (M + 255) / 256;
   const bool big1 = tm * ((I + 255) / 256) >= 256, big2 = tm * ((d + 255) / 256) >= 256;
   const bool fits = (int64_t)d * 512 < 0x7fffffff && (int64_t)I * 512 < 0x7fffffff;
@@ -122,7 +124,7 @@ extern "C" int mio_fused_mlp_fwd(const void* x, const void* w1, const void* b1, 
 static bool gemm_blocked_w_ok(int64_t M, int32_t N, int32_t K, int32_t act) {
   if (act == MIO_ACT_SWIGLU || (mio_gemm_impl() != 0 && mio_gemm_impl() < 5)) return false;
   const bool big = ((M + 255) / 256) * (int64_t)((N + 255) / 256) >= 256;
-  return big && K % 32 == 0 && (int64_t)K * 512 < 0x7fffffff;
+  return big && K % 32 == 0 && K >= 128 && (int64_t)K * 512 < 0x7fffffff && (int64_t)N * 512 < 0x7fffffff;
 }
 
 extern "C" size_t mio_weight_blocked_bytes(int32_t N, int32_t K) {
@@ -173,7 +175,8 @@ extern "C" int mio_gemm_bias_act_bw(const void* x, const void* wb, const void* b
             "mio_gemm_bias_act_bw: bad strides");
   MIO_CHECK(mio_aligned16(x) && mio_aligned16(wb) && mio_aligned16(y) && mio_aligned16(residual) && mio_aligned16(bias),
             "mio_gemm_bias_act_bw: pointers must be 16-byte aligned");
-  MIO_CHECK(ldx * 512 < (int64_t)0x7fffffff, "mio_gemm_bias_act_bw: ldx too large for the blocked-weight kernels");
+  MIO_CHECK(ldx * 512 < (int64_t)0x7fffffff && ldy * 512 < (int64_t)0x7fffffff && (residual == nullptr || ldr * 512 < (int64_t)0x7fffffff),
+            "mio_gemm_bias_act_bw: row stride too large for the blocked-weight kernels");
   MIO_CHECK(gemm_blocked_w_ok(M, N, K, act), "mio_gemm_bias_act_bw: this shape does not take the blocked-weight kernels "
                                              "(mio_gemm_blocked_weight_ok == 0); use mio_gemm_bias_act with the plain weight");
   GemmDev p;
@@ -189,7 +192,7 @@ extern "C" int mio_gemm_bias_act_bw(const void* x, const void* wb, const void* b
 // column scale: the launch must end in the persistent kernel (gemm_inst.hip launch_act): blocked weight shape, no residual,
 // K >= 256, K % 64 == 0
 extern "C" int32_t mio_gemm_col_scale_ok(int64_t M, int32_t N, int32_t K, int32_t act) {
-  return (gemm_blocked_w_ok(M, N, K, act) && mio_gemm_impl() == 0 && K >= 256 && K % 64 == 0 && N % 8 == 0) ? 1 : 0;
+  return (gemm_blocked_w_ok(M, N, K, act) && (mio_gemm_impl() == 0 || mio_gemm_impl() >= 5) && K >= 256 && K % 64 == 0 && N % 8 == 0) ? 1 : 0;
 }
 
 extern "C" int mio_gemm_bias_act_bw_cs(const void* x, const void* wb, const void* bias, void* y, int64_t M, int32_t N,

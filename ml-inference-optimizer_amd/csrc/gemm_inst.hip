@@ -5,6 +5,7 @@
 
 #include "gemm4w16_kernel.h"
 #include "gemm4w16p_kernel.h"
+#include "gemm8w_kernel.h"
 
 #if GEMM_TYPE_ID == 0
 using GT = __bf16;
@@ -39,6 +40,7 @@ static int gemm_var() {  // MIO_GEMM_VAR=<bits>: timing-only ablations of the AC
 }
 #endif
 
+#ifdef MIO_DIAG  // the one-wave-per-SIMD kernels of rounds 1-2: kept in the diagnostic library for A/B runs only
 template <int ACT, int VAR = 0>
 static int launch_4w16(GemmDev p, hipStream_t stream) {
 #ifdef MIO_DIAG
@@ -112,6 +114,40 @@ static int launch_4w16p(GemmDev p, hipStream_t stream) {
   return 0;
 }
 
+#endif  // MIO_DIAG
+
+// eight-wave ping-pong kernel (gemm8w_kernel.h), persistent; `one_tile`: one workgroup per tile instead (A/B only)
+template <int ACT, bool RES, int VAR = 0>
+static int launch_8w(GemmDev p, hipStream_t stream, bool one_tile = false) {
+  constexpr int BN = (ACT == MIO_ACT_SWIGLU) ? 128 : 256;
+  p.tiles_m = (int)((p.M + 255) / 256);
+  p.tiles_n = (p.N + BN - 1) / BN;
+  auto kern = gemm8w_kernel<GT, ACT, RES, VAR>;
+  static std::once_flag once;
+  static hipError_t ea = hipSuccess;
+  static int ncu = 256;
+  std::call_once(once, [&] {
+    ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G8_SMEM);
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      ncu = n & ~7;  // whole XCD groups, so tile % 8 keeps naming the XCD
+  });
+  if (ea != hipSuccess) return mio_fail(std::string("gemm8w: hipFuncSetAttribute: ") + hipGetErrorString(ea));
+  const int tiles = p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL(kern, dim3((one_tile || tiles < ncu) ? tiles : ncu), dim3(G8_THREADS), G8_SMEM, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("gemm8w launch: ") + hipGetErrorString(e));
+  return 0;
+}
+template <int ACT, int VAR = 0>
+static int launch_8w_res(const GemmDev& p, hipStream_t stream, bool one_tile = false) {
+  if constexpr (ACT != MIO_ACT_SWIGLU && VAR == 0) {
+    if (p.res != nullptr) return launch_8w<ACT, true>(p, stream, one_tile);
+  }
+  return launch_8w<ACT, false, VAR>(p, stream, one_tile);
+}
+
 static int gemm_impl() { return mio_gemm_impl(); }  // MIO_GEMM_IMPL (gemm_api.hip)
 
 template <int ACT>
@@ -126,13 +162,25 @@ static int launch_act(const GemmDev& p, hipStream_t stream) {
     const int64_t big = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (big >= 256) {
       if (gemm_impl() == 1) return launch_cfg<256, 256, 2, 4, ACT>(p, stream);
-      // the 16x16x32 kernel addresses operands with 32-bit per-tile byte offsets and needs whole K-tiles
-      const bool fits = (p.K % 32 == 0) && (p.ldx * 512 < (int64_t)0x7fffffff) && (p.ldw * 512 < (int64_t)0x7fffffff);
+      // the 16x16x32 kernels address operands with 32-bit per-tile byte offsets and need whole K-tiles (>= 4 of them)
+      const bool fits = (p.K % 32 == 0) && p.K >= 128 && (p.ldx * 512 < (int64_t)0x7fffffff) &&
+                        (p.ldw * 512 < (int64_t)0x7fffffff) && (p.ldy * 512 < (int64_t)0x7fffffff) &&
+                        (p.res == nullptr || p.ldr * 512 < (int64_t)0x7fffffff);
       if (!fits) return launch_cfg<256, 256, 2, 4, ACT>(p, stream);
-      // no residual: persistent kernel with the overlapped epilogue (MIO_GEMM_IMPL=4w16 keeps the one-tile kernel)
-      if (gemm_impl() != 6 && p.res == nullptr && p.K >= 256 && p.K % 64 == 0 && p.ldy * 512 < (int64_t)0x7fffffff)
-        return launch_4w16p<ACT>(p, stream);
-      return launch_4w16<ACT>(p, stream);
+#ifdef MIO_DIAG
+      if constexpr (ACT == MIO_ACT_NONE) {
+        if (gemm_impl() == 8 && p.dbg != nullptr) return launch_8w<ACT, false, 128>(p, stream);  // stamps
+        if (gemm_impl() == 10) return launch_8w_res<ACT, 4>(p, stream);
+        if (gemm_impl() == 13) return launch_8w_res<ACT, 16>(p, stream);
+        if (gemm_impl() == 16) return launch_8w_res<ACT, 64>(p, stream);
+      }
+      if (gemm_impl() == 9) return launch_8w_res<ACT>(p, stream, true);  // one workgroup per tile
+      if (gemm_impl() == 5 || gemm_impl() == 6) {  // rounds 1-2: persistent where it applied, else one tile per workgroup
+        if (gemm_impl() == 5 && p.res == nullptr && p.K >= 256 && p.K % 64 == 0) return launch_4w16p<ACT>(p, stream);
+        return launch_4w16<ACT>(p, stream);
+      }
+#endif
+      return launch_8w_res<ACT>(p, stream);
     }
     return launch_cfg<128, 128, 2, 2, ACT>(p, stream);
   }

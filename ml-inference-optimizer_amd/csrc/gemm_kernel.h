@@ -70,9 +70,16 @@ __device__ __forceinline__ float gemm_act(float v) {
 // Two values at once with packed fp32 math (v_pk_mul/fma/add_f32): used where no MFMA is in flight (the read-out of
 // the persistent kernel), where packed ops run at twice the rate of the scalar forms.  Same formulas as gemm_act,
 // constants folded: gelu_tanh(v) = v / (1 + 2^(-v (c0 + c1 v^2))), c0 = 2 sqrt(2/pi) log2(e), c1 = 0.044715 c0.
-template <int ACT>
+// SCALAR = true: the plain one-value formulas.  gemm8w_kernel's read-out runs while the SIMD's other wave issues MFMAs, and
+// there the packed form of the exp2 / rcp activations (v_pk_mul / v_pk_add around v_exp_f32 / v_rcp_f32) returned wrong
+// values in lanes 12..15 and 44..47 of one register pair per row pair -- deterministic, unchanged by s_nop padding between
+// the transcendentals and their consumers, gone with the scalar instructions (round 3, MI355X, ROCm 7.2).  The one-wave-
+// per-SIMD kernels, where no MFMA is in flight during the read-out, never showed it and keep the packed form.
+template <int ACT, bool SCALAR = false>
 __device__ __forceinline__ f32x2_t gemm_act2(f32x2_t v) {
-  if constexpr (ACT == MIO_ACT_GELU_TANH) {
+  if constexpr (SCALAR) {
+    return (f32x2_t){gemm_act<ACT>(v[0]), gemm_act<ACT>(v[1])};
+  } else if constexpr (ACT == MIO_ACT_GELU_TANH) {
     constexpr float c0 = 2.0f * 0.7978845608028654f * 1.4426950408889634f, c1 = c0 * 0.044715f;
     const f32x2_t t = v * v;
     const f32x2_t z = -(v * (t * c1 + c0));
