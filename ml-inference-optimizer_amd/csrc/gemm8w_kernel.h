@@ -1,8 +1,7 @@
 // 256x256 bf16/fp16 GEMM on v_mfma_f32_16x16x32 with EIGHT waves per workgroup: two waves on every SIMD, run as a
 // ping-pong -- while one wave of a SIMD issues its MFMAs the other reads its next fragments from LDS and requests the
 // K-tile three ahead (cdna_hip_programming.md, "The 256^2 8-phase template"; MI355X_MICROARCH.md, "Two waves per SIMD").
-// Persistent: a workgroup walks its output tiles, the load stream runs on across tiles, the output leaves as a burst of
-// 16-byte stores that the next tile's first K-tiles cover.
+// Persistent: a workgroup walks its output tiles and the load stream runs on across tiles.
 //
 // Why (round-3 measurements, tools/gemm8_ksweep.py, M 32768 x N 3072, blocked operands): the one-wave-per-SIMD kernels pay
 // issue time for everything that is not an MFMA.  Per K-tile of 32 and workgroup, zero operands (clock 2.39 GHz) / random:
@@ -31,9 +30,23 @@
 //     Three K-tiles stay in flight (vmcnt(8) = the two youngest K-tiles of 4 pieces per wave).
 //   * tile boundary: the last three K-tiles of a tile request K-tiles 0..2 of the workgroup's next tile (the stage index
 //     runs on); the last read segment waits vmcnt(4) (next K-tiles 0 AND 1 landed), so the next tile's first read segment
-//     needs no wait; its second one waits vmcnt(8) as usual, which by then covers the 16 output stores issued in
-//     between (stores and loads retire out of order with each other: only "at most 8 operations of any kind in flight"
-//     says that K-tile 2 has landed).  The first K-tile of a tile multiplies with C = 0: no zeroing pass.
+//     needs no wait.  The first K-tile of a tile multiplies with C = 0: no zeroing pass.
+//   * output: the read-out (bias / activation / column scale / residual, v_permlane16_swap row-pair exchange) stores
+//     16 chunks of 16 bytes per lane at the tile boundary.  The CU's store path takes 16 bytes per clock (73 cycles per
+//     buffer_store_dwordx4 wave-instruction whatever its address pattern): 8.2k cycles per 256x256 tile, 4.7k per group,
+//     the two groups one after the other, against a 34k-cycle K loop at K = 1024.  Trickling the stores through the read
+//     segments of the next tile's K loop (output parked in 32..64 registers, read back by wave-uniform index) was built
+//     and measured SLOWER (QKV 0.191 ms against 0.167 for the burst; with the trickled stores' data dropped by the range
+//     check still 0.181, with no trickled store at all 0.161): a fifth vector-memory instruction in a read segment whose
+//     four LDS-DMA requests already take ~400 of the partner's 535 MFMA cycles queues behind every wave's loads.
+//   * store data must outlive the store: `buffer_store_dwordx4 v[88:91], v93, s[16:19], s0 offen` followed at once by a
+//     VALU write of v88/v89 (hipcc reuses the dead registers for the next chunk) reached memory with the NEW contents in
+//     lanes 12..15 / 44..47 of dword 1 (round 3, MI355X, ROCm 7.2: deterministic, tools/dbg/gemm8_dump.py; LLVM assumes
+//     the register-soffset form has no such hazard).  Every stored chunk is therefore kept live (an empty asm use) until
+//     all 16 stores of the read-out have been issued and 64 wait states have passed.
+//   * activation fragments rotate: the read segment fetches the weight fragments and row tiles 0..3; row tile t + 4 is
+//     read into tile t's registers right behind tile t's four MFMAs (its pieces were requested by this wave's own group,
+//     so the stage is not restaged under those reads): 32 fragment registers instead of 48 pay for the parked output.
 //   * GLU (SwiGLU, reference kernels/triton/mlp_kernels.py:417-641): the weight tile interleaves 32 gate rows and 32 up
 //     rows per wave (mio_weight_block_glu), so accumulator columns 0..31 / 32..63 of a wave are gate / up of the SAME 32
 //     output columns and silu(gate) * up is lane-local; the output tile is 256 x 128.
@@ -47,16 +60,18 @@ constexpr int G8_BIAS_OFF = G6_SMEM;  // 8 waves x 256 B: each wave's slice of t
 constexpr int G8_SMEM = G6_SMEM + 8 * 256;
 
 // VAR (timing-only ablations, diagnostic library): 4 = no prefetch issue in the loop, 16 = no counted wait,
-// 64 = every piece re-reads K-tile 0, 128 = in-kernel stamps (tools/gemm8_stamps.py)
+// 64 = every piece re-reads K-tile 0, 128 = in-kernel stamps (tools/gemm8_stamps.py), 256 = scalar activation math,
+// 2048 = all eight activation fragments read in the read segment
 template <typename T, int ACT, bool RES, int VAR = 0>
 __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
   using X8 = typename DT<T>::x8;
   using X4 = typename DT<T>::x4;
   constexpr bool GLU = (ACT == MIO_ACT_SWIGLU);
-  constexpr bool SAFE_ACT = true;  // scalar activation math (gemm_kernel.h gemm_act2)
+  constexpr bool SCALAR_ACT = (VAR & 256) != 0;  // gemm_kernel.h gemm_act2 (ablation)
   constexpr int BN = GLU ? 128 : 256;  // output columns per tile
   constexpr int WN = BN / 4;           // output columns per wave
   constexpr int ONT = WN / 16;         // output column tiles per wave
+  constexpr int NCH = 4 * ONT;         // 16-byte output chunks per lane and tile: chunk j = (row pair j / ONT, column tile j % ONT)
   static_assert(!(GLU && RES), "no residual on the gated stage");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -74,7 +89,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
   int64_t m0 = 0, mrem = 0;
   int n0 = 0, nrem = 0;  // in OUTPUT columns
   // lane id recomputed from an opaque instruction wherever lane-constant addresses are built inside the tile loop: hoisted
-  // out of it (LICM) they are kept live -- 32 VGPRs of store offsets alone -- and spilled (gemm4w16p_kernel.h)
+  // out of it (LICM) they are kept live and spilled (gemm4w16p_kernel.h)
   auto lane_now = [&]() {
     int l;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
@@ -91,7 +106,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
     const int wrows = GLU ? 256 : nrem;  // GLU weights are blocked and padded: every row of the tile exists
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row = (wave * 2 + i) * 16 + prow;  // 0..255
+      const int row = (wave * 2 + i) * 16 + prow;  // 0..255: waves 0..3 request rows 0..127, waves 4..7 rows 128..255
       const int kch = pcs ^ g6_swz(row);
       const int xr = (row < mrem) ? row : (int)(mrem - 1);
       const int wrw = (row < wrows) ? row : (wrows - 1);
@@ -129,9 +144,13 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
   const int xbase = (grp * 128 + c16) * 64 + co;
   const int wbase = G6_XT + (wn * 64 + c16) * 64 + co;
 
-  X8 fx[8];
+  constexpr bool ROT = (VAR & 2048) == 0;  // (ablation 2048: all eight activation fragments read in the read segment)
+  X8 fx[ROT ? 4 : 8];
   X8 fw[4];
   f32x4_t acc[8][4];
+
+  const int ystep = p.y_blk ? 32 * 64 : 64 * (int)p.ldy;  // bytes per row pair (32 rows)
+  const int ychi = p.y_blk ? 16384 : 64;  // bytes from column tile nt to nt + 2 (blocked: the next 32-column block)
 
   // one K-tile: kt = index inside the current tile (stage (sbase + kt) & 3), kl = the K-tile requested three ahead (of the
   // tile `setup` describes), WAIT = the counted wait of the read segment (8: the next K-tile has landed; 4: the next two)
@@ -141,7 +160,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) fw[nt] = __builtin_bit_cast(X8, *(const u32x4_t*)(buf + wbase + nt * 1024));
 #pragma unroll
-    for (int t = 0; t < 8; ++t) fx[t] = __builtin_bit_cast(X8, *(const u32x4_t*)(buf + xbase + t * 1024));
+    for (int t = 0; t < (ROT ? 4 : 8); ++t) fx[t] = __builtin_bit_cast(X8, *(const u32x4_t*)(buf + xbase + t * 1024));
     __builtin_amdgcn_sched_barrier(0);
     if constexpr ((VAR & 4) == 0) issue_tile(kt + 3, kl);
     __builtin_amdgcn_sched_barrier(0);
@@ -152,17 +171,23 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    // -- MFMA segment
+    // -- MFMA segment: row tile t's four MFMAs, then row tile t + 4 into its fragment registers
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int t = 0; t < 8; ++t) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
+      for (int nt = 0; nt < 4; ++nt) {
         if constexpr (decltype(FIRST)::value != 0)
-          acc[t][nt] = DT<T>::mfma16(fw[nt], fx[t], (f32x4_t){0.f, 0.f, 0.f, 0.f});
+          acc[t][nt] = DT<T>::mfma16(fw[nt], fx[ROT ? (t & 3) : t], (f32x4_t){0.f, 0.f, 0.f, 0.f});
         else
-          acc[t][nt] = DT<T>::mfma16(fw[nt], fx[t], acc[t][nt]);
+          acc[t][nt] = DT<T>::mfma16(fw[nt], fx[ROT ? (t & 3) : t], acc[t][nt]);
       }
+      if (ROT && t < 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        fx[t] = __builtin_bit_cast(X8, *(const u32x4_t*)(buf + xbase + (t + 4) * 1024));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -189,12 +214,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
     // K-tiles 0 .. nk-4 prefetch inside this tile (nk >= 4)
     ktile(0, 3, IC(1), IC(0));
     if constexpr ((VAR & 128) != 0) st[1] = __builtin_amdgcn_s_memtime();
-    for (int kt = 1; kt < nk - 3; ++kt) {
-      ktile(kt, kt + 3, IC(0), IC(8));
-      if constexpr ((VAR & 128) != 0) {
-        if (kt == 1) st[2] = __builtin_amdgcn_s_memtime();
-      }
-    }
+    for (int kt = 1; kt < nk - 3; ++kt) ktile(kt, kt + 3, IC(0), IC(8));
     if constexpr ((VAR & 128) != 0) st[3] = __builtin_amdgcn_s_memtime();
 
     // ---- this wave's output coordinates; from here on `setup` describes the next tile
@@ -230,10 +250,10 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
     sbase = (sbase + nk) & (G6_STAGES - 1);
     if constexpr ((VAR & 128) != 0) st[4] = __builtin_amdgcn_s_memtime();
 
-    // ---- read-out: bias / activation / column scale / residual, row-pair exchange, 16-byte stores.
-    // Stores and residual loads are buffer instructions on a per-tile descriptor (base = the wave tile's first element):
-    // a 32-bit lane offset fixed per tile, the row-pair step in the scalar offset, the column tile in the immediate, and
-    // rows / columns past M / N get an out-of-range offset that the range check drops -- no branches, no 64-bit math.
+    // ---- read-out: bias / activation / column scale (/ residual), row-pair exchange, 16-byte stores.
+    // Residual loads and stores are buffer instructions on a per-tile descriptor (base = the wave tile's first element): a 32-bit lane offset fixed per tile, the row-pair
+    // step in the scalar offset, the column tile in the immediate, and rows / columns past M / N get an out-of-range
+    // offset that the range check drops -- no branches, no 64-bit math.
     {
       const int ln = lane_now(), c16 = ln & 15, g = ln >> 4;  // (shadows the kernel-scope values on purpose)
       u32x2_t bq[4];
@@ -259,7 +279,6 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
       const __amdgpu_buffer_rsrc_t yrs =
           __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.y + (((uint64_t)yhi << 32) | ylo)), 0, 0x7fffffff, 0x00020000);
       const int yvo = p.y_blk ? rS * 64 + 16 * (g >> 1) : (rS * (int)p.ldy + 8 * (g >> 1)) * 2;
-      const int ystep = p.y_blk ? 32 * 64 : 64 * (int)p.ldy;  // bytes per row pair (32 rows)
       __amdgpu_buffer_rsrc_t rrs = yrs;
       int rvo = 0, rstep = 0;
       if constexpr (RES) {
@@ -270,6 +289,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
         rvo = (c16 * (int)p.ldr + 4 * g) * 2;  // accumulator layout: row c16 (+16 for the pair's second tile), columns 4 g ..
         rstep = 64 * (int)p.ldr;
       }
+      u32x4_t keep[NCH];
 #pragma unroll
       for (int mtp = 0; mtp < 4; ++mtp) {
         u32x2_t resA[ONT], resB[ONT];
@@ -295,15 +315,15 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
             const f32x4_t au = acc[2 * mtp][nt + 2], bu = acc[2 * mtp + 1][nt + 2];
             const X4 uv = __builtin_bit_cast(X4, bq[nt + 2]);
             const f32x2_t u01 = {(float)uv[0], (float)uv[1]}, u23 = {(float)uv[2], (float)uv[3]};
-            a01 = gemm_act2<MIO_ACT_SILU, SAFE_ACT>((f32x2_t){a[0], a[1]} + b01) * ((f32x2_t){au[0], au[1]} + u01);
-            a23 = gemm_act2<MIO_ACT_SILU, SAFE_ACT>((f32x2_t){a[2], a[3]} + b23) * ((f32x2_t){au[2], au[3]} + u23);
-            c01 = gemm_act2<MIO_ACT_SILU, SAFE_ACT>((f32x2_t){b[0], b[1]} + b01) * ((f32x2_t){bu[0], bu[1]} + u01);
-            c23 = gemm_act2<MIO_ACT_SILU, SAFE_ACT>((f32x2_t){b[2], b[3]} + b23) * ((f32x2_t){bu[2], bu[3]} + u23);
+            a01 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>((f32x2_t){a[0], a[1]} + b01) * ((f32x2_t){au[0], au[1]} + u01);
+            a23 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>((f32x2_t){a[2], a[3]} + b23) * ((f32x2_t){au[2], au[3]} + u23);
+            c01 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>((f32x2_t){b[0], b[1]} + b01) * ((f32x2_t){bu[0], bu[1]} + u01);
+            c23 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>((f32x2_t){b[2], b[3]} + b23) * ((f32x2_t){bu[2], bu[3]} + u23);
           } else {
-            a01 = gemm_act2<ACT, SAFE_ACT>((f32x2_t){a[0], a[1]} + b01) * cs2;
-            a23 = gemm_act2<ACT, SAFE_ACT>((f32x2_t){a[2], a[3]} + b23) * cs2;
-            c01 = gemm_act2<ACT, SAFE_ACT>((f32x2_t){b[0], b[1]} + b01) * cs2;
-            c23 = gemm_act2<ACT, SAFE_ACT>((f32x2_t){b[2], b[3]} + b23) * cs2;
+            a01 = gemm_act2<ACT, SCALAR_ACT>((f32x2_t){a[0], a[1]} + b01) * cs2;
+            a23 = gemm_act2<ACT, SCALAR_ACT>((f32x2_t){a[2], a[3]} + b23) * cs2;
+            c01 = gemm_act2<ACT, SCALAR_ACT>((f32x2_t){b[0], b[1]} + b01) * cs2;
+            c23 = gemm_act2<ACT, SCALAR_ACT>((f32x2_t){b[2], b[3]} + b23) * cs2;
           }
           if constexpr (RES) {
             const X4 ra = __builtin_bit_cast(X4, resA[nt]), rb = __builtin_bit_cast(X4, resB[nt]);
@@ -312,16 +332,27 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
             c01 += (f32x2_t){(float)rb[0], (float)rb[1]};
             c23 += (f32x2_t){(float)rb[2], (float)rb[3]};
           }
-          uint32_t pa01 = pack2<T>(a01[0], a01[1]), pc01 = pack2<T>(c01[0], c01[1]), pa23 = pack2<T>(a23[0], a23[1]), pc23 = pack2<T>(c23[0], c23[1]);
-          const auto s0 = __builtin_amdgcn_permlane16_swap(pa01, pc01, false, false);
-          const auto s1 = __builtin_amdgcn_permlane16_swap(pa23, pc23, false, false);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(pack2<T>(a01[0], a01[1]), pack2<T>(c01[0], c01[1]), false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(pack2<T>(a23[0], a23[1]), pack2<T>(c23[0], c23[1]), false, false);
           const u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
+          keep[mtp * ONT + nt] = o;
           const bool ok = mok && (full || nt * 16 + 8 * (g >> 1) < onrem);
           const int off = ok ? yvo : 0x7fffffff;  // out of range: dropped by the buffer range check
-          // column tile nt: +32 bytes in a row; blocked: tiles 2, 3 lie in the next 32-column block (16 KiB further)
-          __builtin_amdgcn_raw_buffer_store_b128(o, yrs, off, mtp * ystep + (p.y_blk ? ((nt >> 1) << 14) + ((nt & 1) << 5) : nt * 32), 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o, yrs, off, mtp * ystep + (nt & 1) * 32 + (nt >> 1) * ychi, 0);
         }
       }
+      // no register a store reads is written before the stores have fetched their data (header: store data must outlive ...)
+      if constexpr (NCH == 16)
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                     :
+                     : "v"(keep[0]), "v"(keep[1]), "v"(keep[2]), "v"(keep[3]), "v"(keep[4]), "v"(keep[5]), "v"(keep[6]), "v"(keep[7]),
+                       "v"(keep[8]), "v"(keep[9]), "v"(keep[10]), "v"(keep[11]), "v"(keep[12]), "v"(keep[13]), "v"(keep[14]), "v"(keep[15])
+                     : "memory");
+      else
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                     :
+                     : "v"(keep[0]), "v"(keep[1]), "v"(keep[2]), "v"(keep[3]), "v"(keep[4]), "v"(keep[5]), "v"(keep[6]), "v"(keep[7])
+                     : "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr ((VAR & 128) != 0) {  // per (tile, wave): start, K-tile 0 / 1 done, tail start, loop end, read-out end; 100 MHz
@@ -336,5 +367,6 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
     tile = next;
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
 #undef IC
 }

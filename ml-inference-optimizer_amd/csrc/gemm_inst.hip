@@ -170,9 +170,13 @@ static int launch_act(const GemmDev& p, hipStream_t stream) {
 #ifdef MIO_DIAG
       if constexpr (ACT == MIO_ACT_NONE) {
         if (gemm_impl() == 8 && p.dbg != nullptr) return launch_8w<ACT, false, 128>(p, stream);  // stamps
+        if (gemm_impl() == 24) return launch_8w_res<ACT, 2048>(p, stream);
         if (gemm_impl() == 10) return launch_8w_res<ACT, 4>(p, stream);
         if (gemm_impl() == 13) return launch_8w_res<ACT, 16>(p, stream);
         if (gemm_impl() == 16) return launch_8w_res<ACT, 64>(p, stream);
+      }
+      if constexpr (ACT == MIO_ACT_GELU_TANH) {
+        if (gemm_impl() == 20) return launch_8w<ACT, false, 256>(p, stream);  // scalar activation math
       }
       if (gemm_impl() == 9) return launch_8w_res<ACT>(p, stream, true);  // one workgroup per tile
       if (gemm_impl() == 5 || gemm_impl() == 6) {  // rounds 1-2: persistent where it applied, else one tile per workgroup

@@ -70,11 +70,8 @@ __device__ __forceinline__ float gemm_act(float v) {
 // Two values at once with packed fp32 math (v_pk_mul/fma/add_f32): used where no MFMA is in flight (the read-out of
 // the persistent kernel), where packed ops run at twice the rate of the scalar forms.  Same formulas as gemm_act,
 // constants folded: gelu_tanh(v) = v / (1 + 2^(-v (c0 + c1 v^2))), c0 = 2 sqrt(2/pi) log2(e), c1 = 0.044715 c0.
-// SCALAR = true: the plain one-value formulas.  gemm8w_kernel's read-out runs while the SIMD's other wave issues MFMAs, and
-// there the packed form of the exp2 / rcp activations (v_pk_mul / v_pk_add around v_exp_f32 / v_rcp_f32) returned wrong
-// values in lanes 12..15 and 44..47 of one register pair per row pair -- deterministic, unchanged by s_nop padding between
-// the transcendentals and their consumers, gone with the scalar instructions (round 3, MI355X, ROCm 7.2).  The one-wave-
-// per-SIMD kernels, where no MFMA is in flight during the read-out, never showed it and keep the packed form.
+// SCALAR = true: the plain one-value formulas (A/B only: wrong stores first blamed on the packed forms turned out to be store
+// data overwritten behind the store instruction, gemm8w_kernel.h).
 template <int ACT, bool SCALAR = false>
 __device__ __forceinline__ f32x2_t gemm_act2(f32x2_t v) {
   if constexpr (SCALAR) {

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "ml-inference-optimizer_amd"))
 from mio import ops, _lib
 _lib.lib.mio_dbg_set(4, int(sys.argv[1]) if len(sys.argv) > 1 else 8)
 torch.manual_seed(0)
-for (M, N, K, act, bias) in [(8192, 8192, 512, "gelu", True)]:
+for (M, N, K, act, bias) in [(8192, 8192, 512, "gelu", True), (4101, 4096, 512, "gelu_erf", True), (4101, 4104, 1024, "silu", True), (32768, 3072, 1024, "none", True), (8192, 8192, 128, "relu", False), (8200, 8192, 256, "none", True)]:
     x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     w = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
     b = (torch.randn(N, device="cuda") * 0.02).to(torch.bfloat16) if bias else None
