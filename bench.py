@@ -145,14 +145,14 @@ def kernel_rooflines(model, x, iters=10):
     out["fa3_fwd5_kernel<bf16,causal>" if kpre else "fa3_fwd4_kernel<bf16,causal>"] = dict(ms=t, launches=1, flops=2.0 * B * S * (S + 1) * d)
 
     t = _events_ms(lambda: ops.gemm_bias_act(ln1, wqkv, bqkv, out=o3, w_blocked=wqkv_b, col_scale=cs), iters)
-    out["gemm4w16p_kernel<bf16,none>"] = dict(ms=t, launches=1, flops=2.0 * M * d * 3 * d)  # qkv
-    # the MLP as the model runs it: fc1 + GELU (persistent kernel) writes the blocked intermediate, fc2 + residual reads it
+    out["gemm8w_kernel<bf16,none> (qkv)"] = dict(ms=t, launches=1, flops=2.0 * M * d * 3 * d)
+    # the MLP as the model runs it: fc1 + GELU writes the blocked intermediate, fc2 + residual reads it
     t = _events_ms(lambda: ops.fused_mlp(ln2, w1, b1, w2, b2, "gelu", residual=att, fc1_blocked=w1_b, fc2_blocked=w2_b), iters)
-    out["fused_mlp: gemm4w16p_kernel<bf16,gelu_tanh> + gemm4w16_kernel<bf16,none>"] = dict(
+    out["fused_mlp: gemm8w_kernel<bf16,gelu_tanh> + gemm8w_kernel<bf16,none,residual>"] = dict(
         ms=t, launches=2, flops=4.0 * M * d * I, combined=True)  # two different kernels: not a roofline candidate
     t = _events_ms(lambda: ops.gemm_bias_act(ctx, wo, bo, residual=x, out=o1, w_blocked=wo_b,
                                              x_blocked_shape=(B, S, d) if oblk else None), iters)
-    out["gemm4w16_kernel<bf16,none> (out-proj)"] = dict(ms=t, launches=1, flops=2.0 * M * d * d)
+    out["gemm8w_kernel<bf16,none,residual> (out-proj)"] = dict(ms=t, launches=1, flops=2.0 * M * d * d)
     t = _events_ms(lambda: ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias), iters)
     out["layernorm_kernel<bf16>"] = dict(ms=2 * t, launches=2, bytes=2 * 2.0 * M * d * 2)
     return out
@@ -179,6 +179,30 @@ def decode_leg(dt):
             "kernel": "decode_rows_kernel + decode_reduce_kernel", "bound": "hbm", "ms": ms, "achieved": gbs,
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "bytes_per_launch": nbytes,
             "tokens_per_s": Bd / (ms * 1e-3)}
+
+
+def swiglu_leg(dt):
+    """FusedMLP-SwiGLU at the C2 shape (M 32768, d 1024, I 4096; 6 M d I FLOPs): the gated form of gemm8w_kernel on the
+    interleaved gate / up blocked weight + fc2 with bias and residual (reference mlp_kernels.py:417-641)."""
+    import torch
+    from mio import ops
+
+    B, S, d, I = 8, 4096, 1024, 4096
+    M = B * S
+    torch.manual_seed(11)
+    x = torch.randn(B, S, d, device="cuda", dtype=dt)
+    r = torch.randn(B, S, d, device="cuda", dtype=dt)
+    wu, wg = ((torch.randn(I, d, device="cuda") * 0.02).to(dt) for _ in range(2))
+    w2 = (torch.randn(d, I, device="cuda") * 0.02).to(dt)
+    bu, bg = ((torch.randn(I, device="cuda") * 0.02).to(dt) for _ in range(2))
+    b2 = (torch.randn(d, device="cuda") * 0.02).to(dt)
+    blocked = ops.fused_mlp_blocked_weight_ok(M, d, I, "swiglu")
+    kw = dict(fc1_blocked=ops.block_weight_glu(wg, wu), fc2_blocked=ops.block_weight(w2)) if blocked else {}
+    ms = _events_ms(lambda: ops.fused_mlp(x, wu, bu, w2, b2, "swiglu", wg, bg, residual=r, **kw), 10)
+    flops = 6.0 * M * d * I
+    return {"workload": f"FusedMLP swiglu M={M} d={d} I={I} + bias + residual (two launches)", "blocked_weights": bool(blocked),
+            "kernel": "gemm8w_kernel<bf16,swiglu> + gemm8w_kernel<bf16,none,residual>", "ms": ms,
+            "tflops": flops / (ms * 1e-3) / 1e12, "mfma_roofline_frac": flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
 
 
 def c5_leg(dt, steps=3):
@@ -390,7 +414,7 @@ def main():
         del model
         torch.cuda.empty_cache()
         extra = res.setdefault("extra", {})
-        for name, leg in (("decode_roofline", lambda: decode_leg(dt)), ("c5", lambda: c5_leg(dt))):
+        for name, leg in (("decode_roofline", lambda: decode_leg(dt)), ("c5", lambda: c5_leg(dt)), ("swiglu", lambda: swiglu_leg(dt))):
             try:
                 extra[name] = leg()
             except Exception as ex:

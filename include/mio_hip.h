@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MIO_VERSION 102 /* 0.1.0 */
+#define MIO_VERSION 103 /* 0.1.0 */
 
 typedef enum { MIO_BF16 = 0, MIO_FP16 = 1 } mio_dtype_t;
 
@@ -165,6 +165,18 @@ int32_t mio_fused_mlp_blocked_weight_ok(int64_t M, int32_t d, int32_t I, int32_t
 int mio_fused_mlp_fwd_bw(const void* x, const void* w1b, const void* b1, const void* w2b, const void* b2,
                          const void* residual, void* y, void* workspace, int64_t M, int32_t d, int32_t I, int32_t act,
                          int32_t dtype, int32_t x_blocked, void* stream);
+/* SwiGLU on the 256x256-tile kernels (reference kernels/triton/mlp_kernels.py:417-641 _fused_mlp_swiglu_kernel;
+ * kernels/mlp/fused_mlp.py:262-275): the gate and up weights [I, K] are repacked ONCE into one blocked weight whose 256-row
+ * tiles interleave, per 64-row wave slice, 32 gate rows and the 32 up rows of the same output columns
+ *   row (tn * 256 + wn * 64 + h * 32 + j)  <-  (h ? w_up : w_gate)[tn * 128 + wn * 32 + j],   rows padded with zeros,
+ * so that silu(gate) * up is local to a lane of the accumulator and stage 1 writes act once.  Use where
+ * mio_fused_mlp_blocked_weight_ok(M, d, I, MIO_ACT_SWIGLU) != 0; w2b is mio_weight_block(w2). */
+size_t mio_weight_blocked_glu_bytes(int32_t I, int32_t K);
+int mio_weight_block_glu(const void* w_gate, const void* w_up, int64_t ldw, void* wb, int32_t I, int32_t K, int32_t dtype,
+                         void* stream);
+int mio_fused_mlp_glu_fwd_bw(const void* x, const void* wgu_b, const void* b_up, const void* b_gate, const void* w2b,
+                             const void* b2, const void* residual, void* y, void* workspace, int64_t M, int32_t d, int32_t I,
+                             int32_t dtype, int32_t x_blocked, void* stream);
 /* x_blocked != 0: the activation operand x is in the same blocked layout (m in the place of n; ceil(M/256)*256 x K
  * elements, ldx ignored) -- what mio_layernorm_fwd_bx writes, so that LayerNorm -> GEMM hands over contiguous K-tiles. */
 int mio_layernorm_fwd_bx(const void* x, const void* residual, const void* weight, const void* bias, void* yb,

@@ -65,8 +65,9 @@ extern "C" int mio_gemm_bias_act(const void* x, const void* w, const void* bias,
 // then the intermediate can use the blocked layout (GemmDev::x_blk / y_blk).
 static bool mlp_blocked_ok(int64_t M, int32_t d, int32_t I, int32_t act, bool residual) {
   (void)residual;
-  if (act == MIO_ACT_SWIGLU || (mio_gemm_impl() != 0 && mio_gemm_impl() < 5)) return false;
+  if (mio_gemm_impl() != 0 && mio_gemm_impl() < 5) return false;
   const int64_t tm = (M + 255) / 256;
+  // (SwiGLU: stage 1 computes 256 x 128 output tiles from 256 interleaved gate / up weight rows, gemm8w_kernel.h)
   const bool big1 = tm * ((I + 255) / 256) >= 256, big2 = tm * ((d + 255) / 256) >= 256;
   const bool fits = (int64_t)d * 512 < 0x7fffffff && (int64_t)I * 512 < 0x7fffffff;
   return big1 && big2 && fits && d % 64 == 0 && d >= 256 && I % 256 == 0 && d % 8 == 0;
@@ -83,25 +84,27 @@ static int fused_mlp_impl(const void* x, const void* w1, const void* b1, const v
                           int32_t act, int32_t dtype, void* stream, int wblk, int xblk = 0) {
   MIO_CHECK(workspace != nullptr || M == 0, "mio_fused_mlp_fwd: workspace must be non-null");
   MIO_CHECK(act != MIO_ACT_NONE, "mio_fused_mlp_fwd: an activation is required");
-  if (M > 0 && mlp_blocked_ok(M, d, I, act, residual != nullptr)) {
+  if (M > 0 && mlp_blocked_ok(M, d, I, act, residual != nullptr) && (act != MIO_ACT_SWIGLU || wblk)) {
     MIO_CHECK(x && w1 && w2 && y, "mio_fused_mlp_fwd: x, w1, w2, y must be non-null");
     MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_fused_mlp_fwd: dtype must be bf16 or fp16");
     MIO_CHECK(mio_aligned16(x) && mio_aligned16(w1) && mio_aligned16(w2) && mio_aligned16(y) && mio_aligned16(b1) &&
                   mio_aligned16(b2) && mio_aligned16(residual) && mio_aligned16(workspace),
               "mio_fused_mlp_fwd: pointers must be 16-byte aligned");
+    MIO_CHECK(act != MIO_ACT_SWIGLU || wblk, "mio_fused_mlp_fwd: the gated 256-tile kernel takes the interleaved blocked weight "
+                                            "(mio_weight_block_glu) through mio_fused_mlp_glu_fwd_bw");
     GemmDev p;
-    p.x = x; p.w = w1; p.wg = nullptr; p.bias = b1; p.bias_g = nullptr; p.res = nullptr; p.y = workspace;
+    p.x = x; p.w = w1; p.wg = nullptr; p.bias = b1; p.bias_g = bg; p.res = nullptr; p.y = workspace;
     p.M = M; p.ldx = d; p.ldw = d; p.ldy = I; p.ldr = 0; p.N = I; p.K = d;
     p.tiles_m = p.tiles_n = 0;
-    p.x_blk = xblk; p.y_blk = 1; p.w_blk = wblk;
+    p.x_blk = xblk; p.y_blk = 1; p.w_blk = (act == MIO_ACT_SWIGLU) ? 2 : wblk;  // 2: gate / up rows interleaved per wave
     p.dbg = nullptr;
     p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f;
     int rc = gemm_dispatch(p, act, dtype, (hipStream_t)stream);
     if (rc != 0) return rc;
-    p.x = workspace; p.w = w2; p.bias = b2; p.res = residual; p.y = y;
+    p.x = workspace; p.w = w2; p.bias = b2; p.bias_g = nullptr; p.res = residual; p.y = y;
     p.ldx = I; p.ldw = I; p.ldy = d; p.ldr = d; p.N = d; p.K = I;
     p.tiles_m = p.tiles_n = 0;
-    p.x_blk = 1; p.y_blk = 0;
+    p.x_blk = 1; p.y_blk = 0; p.w_blk = wblk;
     return gemm_dispatch(p, MIO_ACT_NONE, dtype, (hipStream_t)stream);
   }
   MIO_CHECK(!wblk && !xblk, "mio_fused_mlp_fwd_bw: this shape does not take the blocked-weight kernels "
@@ -229,5 +232,52 @@ extern "C" int mio_fused_mlp_fwd_bw(const void* x, const void* w1b, const void* 
                                     const void* residual, void* y, void* workspace, int64_t M, int32_t d, int32_t I,
                                     int32_t act, int32_t dtype, int32_t x_blocked, void* stream) {
   return fused_mlp_impl(x, w1b, b1, nullptr, nullptr, w2b, b2, residual, y, workspace, M, d, I, act, dtype, stream, 1,
+                        x_blocked ? 1 : 0);
+}
+
+// ---- SwiGLU on the 256-tile kernel: gate / up weights interleaved per wave in one blocked weight ----------------------
+extern "C" size_t mio_weight_blocked_glu_bytes(int32_t I, int32_t K) {
+  return (size_t)((I + 127) / 128 * 256) * (size_t)K * 2;
+}
+
+// one 16-byte chunk per thread: destination unit u = ((tn * nk + kt) * 256 + row) * 4 + chunk, row = wn * 64 + h * 32 + j
+// <- row tn * 128 + wn * 32 + j of the gate (h = 0) or up (h = 1) weight
+__global__ void weight_block_glu_kernel(const uint16_t* __restrict__ wg, const uint16_t* __restrict__ wu, int64_t ldw,
+                                        uint16_t* __restrict__ wb, int I, int K, int64_t units) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= units) return;
+  const int nk = K / 32;
+  const int chunk = (int)(u & 3), row = (int)((u >> 2) & 255);
+  const int64_t blk = u >> 10;
+  const int kt = (int)(blk % nk), tn = (int)(blk / nk);
+  const int n = tn * 128 + (row >> 6) * 32 + (row & 31);
+  const uint16_t* src = ((row >> 5) & 1) ? wu : wg;
+  u32x4_t v = {0u, 0u, 0u, 0u};
+  if (n < I) v = *(const u32x4_t*)(src + (int64_t)n * ldw + kt * 32 + chunk * 8);
+  *(u32x4_t*)(wb + u * 8) = v;
+}
+
+extern "C" int mio_weight_block_glu(const void* w_gate, const void* w_up, int64_t ldw, void* wb, int32_t I, int32_t K,
+                                    int32_t dtype, void* stream) {
+  MIO_CHECK(w_gate && w_up && wb, "mio_weight_block_glu: w_gate, w_up and wb must be non-null");
+  MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_weight_block_glu: dtype must be bf16 or fp16");
+  MIO_CHECK(I > 0 && K > 0 && K % 32 == 0 && ldw >= K && ldw % 8 == 0, "mio_weight_block_glu: need K % 32 == 0, ldw % 8 == 0");
+  MIO_CHECK(mio_aligned16(w_gate) && mio_aligned16(w_up) && mio_aligned16(wb), "mio_weight_block_glu: pointers must be 16-byte aligned");
+  const int64_t units = (int64_t)((I + 127) / 128) * (K / 32) * 1024;
+  hipLaunchKernelGGL(weight_block_glu_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)w_gate, (const uint16_t*)w_up, ldw, (uint16_t*)wb, I, K, units);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("mio_weight_block_glu launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int mio_fused_mlp_glu_fwd_bw(const void* x, const void* wgu_b, const void* b_up, const void* b_gate, const void* w2b,
+                                        const void* b2, const void* residual, void* y, void* workspace, int64_t M, int32_t d,
+                                        int32_t I, int32_t dtype, int32_t x_blocked, void* stream) {
+  MIO_CHECK(mio_aligned16(b_gate), "mio_fused_mlp_glu_fwd_bw: pointers must be 16-byte aligned");
+  MIO_CHECK(M == 0 || mlp_blocked_ok(M, d, I, MIO_ACT_SWIGLU, false),
+            "mio_fused_mlp_glu_fwd_bw: this shape does not take the 256-tile kernels (mio_fused_mlp_blocked_weight_ok(.., SWIGLU) == 0); "
+            "pass the plain weights to mio_fused_mlp_fwd");
+  return fused_mlp_impl(x, wgu_b, b_up, nullptr, b_gate, w2b, b2, residual, y, workspace, M, d, I, MIO_ACT_SWIGLU, dtype, stream, 1,
                         x_blocked ? 1 : 0);
 }

@@ -42,6 +42,9 @@ EXPORTS = (
     "mio_gemm_bias_act_bw_cs",
     "mio_fused_mlp_blocked_weight_ok",
     "mio_fused_mlp_fwd_bw",
+    "mio_weight_blocked_glu_bytes",
+    "mio_weight_block_glu",
+    "mio_fused_mlp_glu_fwd_bw",
     "mio_layernorm_fwd_bx",
     "mio_layernorm_fwd",
     "mio_fa3_decode_workspace_bytes",
@@ -127,6 +130,12 @@ def _load() -> C.CDLL:
     lib.mio_fused_mlp_blocked_weight_ok.restype = i32
     lib.mio_fused_mlp_fwd_bw.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]
     lib.mio_fused_mlp_fwd_bw.restype = i32
+    lib.mio_weight_blocked_glu_bytes.argtypes = [i32, i32]
+    lib.mio_weight_blocked_glu_bytes.restype = C.c_size_t
+    lib.mio_weight_block_glu.argtypes = [vp, vp, i64, vp, i32, i32, i32, vp]
+    lib.mio_weight_block_glu.restype = i32
+    lib.mio_fused_mlp_glu_fwd_bw.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+    lib.mio_fused_mlp_glu_fwd_bw.restype = i32
     lib.mio_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]
     lib.mio_layernorm_fwd.restype = i32
     lib.mio_layernorm_fwd_bx.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]

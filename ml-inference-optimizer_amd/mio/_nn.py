@@ -63,6 +63,20 @@ class CastCache:
         return t
 
 
+def _get_blocked_glu(self, gate: torch.Tensor, up: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """The SwiGLU gate / up parameters as ONE interleaved blocked weight (ops.block_weight_glu), repacked when either changes."""
+    key = (gate.data_ptr(), gate._version, up.data_ptr(), up._version, dtype, gate.device, "blocked_glu")
+    hit = self._c.get(("g", id(gate), id(up)))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    t = ops.block_weight_glu(self.get(gate, dtype), self.get(up, dtype))
+    self._c[("g", id(gate), id(up))] = (key, t)
+    return t
+
+
+CastCache.get_blocked_glu = _get_blocked_glu
+
+
 def linear(x: torch.Tensor, lin: nn.Linear, cache: CastCache, dtype: torch.dtype, activation: str = "none",
            residual: Optional[torch.Tensor] = None, col_scale=None, x_blocked_shape=None) -> torch.Tensor:
     """F.linear(x, W, b) (+ activation, + residual) on the MFMA GEMM.  At sizes that run the 256x256-tile kernels the

@@ -77,8 +77,12 @@ class FusedMLP(nn.Module):
         gw, gb = self._gate(dt)
         M, d, I = x.numel() // x.shape[-1], x.shape[-1], self.fc1.weight.shape[0]
         b1 = b2 = None  # blocked weight copies, when this shape runs the kernels that take them
-        if gw is None and ops.fused_mlp_blocked_weight_ok(M, d, I, act):
-            b1, b2 = c.get_blocked(self.fc1.weight, dt), c.get_blocked(self.fc2.weight, dt)
+        if ops.fused_mlp_blocked_weight_ok(M, d, I, act):
+            if gw is None:
+                b1 = c.get_blocked(self.fc1.weight, dt)
+            else:  # SwiGLU: gate and up rows interleaved in one blocked weight (ops.block_weight_glu)
+                b1 = c.get_blocked_glu(self.fc1_gate.weight, self.fc1.weight, dt)
+            b2 = c.get_blocked(self.fc2.weight, dt)
         xshape = None
         if pre_norm is not None:
             lw, lb = c.get(pre_norm.weight, dt), c.get(pre_norm.bias, dt)

@@ -329,6 +329,25 @@ def block_weight(w: torch.Tensor) -> torch.Tensor:
     return wb
 
 
+def block_weight_glu(w_gate: torch.Tensor, w_up: torch.Tensor) -> torch.Tensor:
+    """One-time repack of the SwiGLU gate / up weights [I, K] (K % 32 == 0) into ONE blocked weight whose 256-row tiles
+    interleave 32 gate rows and the 32 up rows of the same output columns per wave slice (include/mio_hip.h):
+    returns a [ceil(I/128)*256, K] tensor.  fused_mlp(..., activation="swiglu", fc1_blocked=<this>)."""
+    _need_cuda(w_gate, w_up)
+    if w_gate.dim() != 2 or w_gate.shape != w_up.shape or w_gate.shape[1] % 32 != 0 or w_gate.dtype != w_up.dtype:
+        raise ValueError(f"block_weight_glu needs two 2-D weights of one shape and dtype with K % 32 == 0, got "
+                         f"{tuple(w_gate.shape)} / {tuple(w_up.shape)}")
+    w_gate, w_up = _rows16(w_gate), _rows16(w_up)
+    if w_gate.stride(0) != w_up.stride(0):
+        w_gate, w_up = w_gate.contiguous(), w_up.contiguous()
+    I, K = w_gate.shape
+    wb = torch.empty((I + 127) // 128 * 256, K, dtype=w_gate.dtype, device=w_gate.device)
+    assert wb.numel() * wb.element_size() == lib.mio_weight_blocked_glu_bytes(I, K)
+    check(lib.mio_weight_block_glu(w_gate.data_ptr(), w_up.data_ptr(), w_gate.stride(0), wb.data_ptr(), I, K,
+                                   _dtype_id(w_gate), _stream()))
+    return wb
+
+
 def blocked_weight_ok(M: int, N: int, K: int, activation: str = "none") -> bool:
     """True iff a GEMM of this shape runs a kernel that takes blocked weights (w_blocked= below).
     MIO_NO_BLOCKED_W=1 (A/B runs) keeps the modules on the plain weights."""
@@ -430,6 +449,16 @@ def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_g
     return out
 
 
+def _blocked_sizes_ok(fc1_blocked, fc2_blocked, x, d, I, act):
+    """The blocked copies travel as raw pointers: refuse a stale repack (other dtype / device / shape)."""
+    n1 = (I + 127) // 128 * 256 * d if act == _lib.ACT_SWIGLU else (I + 255) // 256 * 256 * d
+    n2 = (d + 255) // 256 * 256 * I
+    for t, n, what in ((fc1_blocked, n1, "fc1_blocked"), (fc2_blocked, n2, "fc2_blocked")):
+        if t.dtype != x.dtype or t.device != x.device or t.numel() != n or not t.is_contiguous():
+            raise ValueError(f"{what}: expected {n} contiguous elements of the input's dtype on its device "
+                             f"(swiglu: block_weight_glu(gate, up)); repack after converting the module")
+
+
 def fused_mlp(
     hidden_states: torch.Tensor,
     fc1_weight: torch.Tensor,
@@ -461,11 +490,18 @@ def fused_mlp(
         _res_ok(residual, M * d, hidden_states.dtype)
         if fc1_blocked is None or fc2_blocked is None or not lib.mio_fused_mlp_blocked_weight_ok(M, d, I, act):
             raise ValueError("a blocked activation operand needs blocked weights and fused_mlp_blocked_weight_ok()")
+        _blocked_sizes_ok(fc1_blocked, fc2_blocked, hidden_states, d, I, act)
         out = torch.empty(*x_blocked_shape, dtype=hidden_states.dtype, device=hidden_states.device)
         work = torch.empty((M + 255) // 256 * 256, I, dtype=hidden_states.dtype, device=hidden_states.device)
         r2 = None if residual is None else residual.reshape(-1, d)
         if r2 is not None and not r2.is_contiguous():
             r2 = r2.contiguous()
+        if act == _lib.ACT_SWIGLU:
+            _vec_ok(fc1_gate_bias, I, hidden_states.dtype, "fc1_gate_bias")
+            check(lib.mio_fused_mlp_glu_fwd_bw(hidden_states.data_ptr(), fc1_blocked.data_ptr(), _ptr(fc1_bias),
+                                               _ptr(fc1_gate_bias), fc2_blocked.data_ptr(), _ptr(fc2_bias), _ptr(r2),
+                                               out.data_ptr(), work.data_ptr(), M, d, I, _dtype_id(hidden_states), 1, _stream()))
+            return out
         check(lib.mio_fused_mlp_fwd_bw(hidden_states.data_ptr(), fc1_blocked.data_ptr(), _ptr(fc1_bias),
                                        fc2_blocked.data_ptr(), _ptr(fc2_bias), _ptr(r2), out.data_ptr(), work.data_ptr(),
                                        M, d, I, act, _dtype_id(hidden_states), 1, _stream()))
@@ -501,6 +537,12 @@ def fused_mlp(
     gate_w = fc1_gate_weight if act == _lib.ACT_SWIGLU else None
     gate_b = fc1_gate_bias if act == _lib.ACT_SWIGLU else None
     if fc1_blocked is not None and fc2_blocked is not None and lib.mio_fused_mlp_blocked_weight_ok(M, d, I, act):
+        _blocked_sizes_ok(fc1_blocked, fc2_blocked, hidden_states, d, I, act)
+        if act == _lib.ACT_SWIGLU:
+            check(lib.mio_fused_mlp_glu_fwd_bw(x2.data_ptr(), fc1_blocked.data_ptr(), _ptr(fc1_bias), _ptr(gate_b),
+                                               fc2_blocked.data_ptr(), _ptr(fc2_bias), _ptr(r2), out.data_ptr(),
+                                               work.data_ptr(), M, d, I, dt, 0, _stream()))
+            return out
         check(lib.mio_fused_mlp_fwd_bw(x2.data_ptr(), fc1_blocked.data_ptr(), _ptr(fc1_bias), fc2_blocked.data_ptr(),
                                        _ptr(fc2_bias), _ptr(r2), out.data_ptr(), work.data_ptr(), M, d, I, act, dt,
                                        0, _stream()))

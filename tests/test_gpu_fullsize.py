@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PARITY = {}
-# bf16 bars against the fp32 truth rounded to bf16 (what profiles/parity_r02.json shows, with margin)
+# bf16 bars against the fp32 truth rounded to bf16 (what profiles/parity_r03.json shows, with margin)
 BF16_REL = 3e-3
 ORACLE_ROWS = 256
 
@@ -38,7 +38,7 @@ def _dump_parity():
     yield
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "parity_r02.json"), "w") as f:
+    with open(os.path.join(out, "parity_r03.json"), "w") as f:
         json.dump(PARITY, f, indent=1, sort_keys=True)
 
 
@@ -179,6 +179,139 @@ def test_c2_fused_mlp_bench_shape():
     truth1 = _gelu_tanh(xn.float().view(M, d) @ w1.float().T + b1.float())
     ref1 = F.gelu(F.linear(xn, w1, b1), approximate="tanh").view(M, I)
     _record("c2_fc1+gelu M32768 N4096 K1024", h1, truth1, ref1)
+
+
+def test_c2_fused_mlp_swiglu_bench_shape():
+    """FusedMLP-SwiGLU at the C2 shape (M 32768, d 1024, I 4096: 6 M d I FLOPs) on the 256-tile path: stage 1 = the gated
+    form of gemm8w_kernel on the interleaved gate / up blocked weight (ops.block_weight_glu) writing the blocked
+    intermediate, stage 2 = fc2 + bias + residual.  Reference: kernels/mlp/fused_mlp.py:262-275, mlp_kernels.py:417-641."""
+    ops = _ops()
+    B, S, d, I = C2["B"], C2["S"], C2["d"], C2["I"]
+    M = B * S
+    x, r = _c2_inputs(40, (B, S, d), (B, S, d))
+    wu, wg, w2 = _c2_inputs(41, (I, d), (I, d), (d, I), scale=0.02)
+    bu, bg, b2 = _c2_inputs(42, (I,), (I,), (d,), scale=0.02)
+    assert ops.fused_mlp_blocked_weight_ok(M, d, I, "swiglu")
+    wgu = ops.block_weight_glu(wg, wu)
+    w2b = ops.block_weight(w2)
+    y = ops.fused_mlp(x, wu, bu, w2, b2, "swiglu", wg, bg, residual=r, fc1_blocked=wgu, fc2_blocked=w2b)
+    xb = ops.block_weight(x.view(M, d))  # the blocked activation layout (what LayerNorm's blocked output is)
+    yb = ops.fused_mlp(xb, wu, bu, w2, b2, "swiglu", wg, bg, residual=r, fc1_blocked=wgu, fc2_blocked=w2b,
+                       x_blocked_shape=(B, S, d))
+    assert torch.equal(y, yb)
+    xf = x.float().view(M, d)
+    h = F.silu(xf @ wg.float().T + bg.float()) * (xf @ wu.float().T + bu.float())
+    truth = h @ w2.float().T + b2.float() + r.float().view(M, d)
+    del h
+    ref16 = (F.linear(F.silu(F.linear(x, wg, bg)) * F.linear(x, wu, bu), w2, b2) + r).view(M, d)
+    name = "c2_fused_mlp swiglu M32768 d1024 I4096 +residual"
+    _record(name, y.view(M, d), truth, ref16, extra=dict(blocked_weights=True))
+    rows = _sample_rows(M, seed=6)
+    want = oracle.fused_mlp(x.view(M, d)[rows].cpu(), wu.cpu(), bu.cpu(), w2.cpu(), b2.cpu(), "swiglu", wg.cpu(), bg.cpu(),
+                            residual=r.view(M, d)[rows].cpu())
+    _oracle_rows(name, y.view(M, d)[rows], want, torch.bfloat16)
+    # the module takes the same path (gate / up repacked once per parameter version)
+    from mio.kernels.mlp import FusedMLPSwiGLU, FusedMLPConfig
+    mod = FusedMLPSwiGLU(d, I, FusedMLPConfig(precision="bf16")).to(DEV).to(torch.bfloat16).eval()
+    with torch.no_grad():
+        mod.fc1.weight.copy_(wu); mod.fc1.bias.copy_(bu); mod.fc1_gate.weight.copy_(wg); mod.fc1_gate.bias.copy_(bg)
+        mod.fc2.weight.copy_(w2); mod.fc2.bias.copy_(b2)
+        assert torch.equal(mod(x, r), y)
+
+
+@pytest.mark.parametrize("tp", [2, 4])
+def test_c3_tensor_parallel_rank_shapes(tp):
+    """The per-rank GEMMs of BASELINE config 3 (tensor_parallel_size 2 / 4) at the full M = 32768: column-parallel QKV
+    (N 3 d / tp, one fused launch as TensorParallelAttention issues it) and fc1 + GELU (N I / tp), row-parallel out-projection
+    (K d / tp) and fc2 (K I / tp) with bias and residual as rank 0 applies them.  tp 4: QKV is 3 tile columns, the
+    out-projection K = 256 is eight K-tiles deep."""
+    ops = _ops()
+    B, S, d, I = C2["B"], C2["S"], C2["d"], C2["I"]
+    M = B * S
+    cases = [("qkv", 3 * d // tp, d, "none", False), ("fc1+gelu", I // tp, d, "gelu", False),
+             ("out_proj", d, d // tp, "none", True), ("fc2", d, I // tp, "none", True)]
+    for i, (what, N, K, act, res) in enumerate(cases):
+        x, = _c2_inputs(50 + 10 * tp + i, (M, K))
+        w, = _c2_inputs(60 + 10 * tp + i, (N, K), scale=0.02)
+        b, = _c2_inputs(70 + 10 * tp + i, (N,), scale=0.02)
+        r = _c2_inputs(80 + 10 * tp + i, (M, N))[0] if res else None
+        assert ops.blocked_weight_ok(M, N, K, act), (what, N, K)
+        y = ops.gemm_bias_act(x, w, b, act, residual=r, w_blocked=ops.block_weight(w))
+        truth = x.float() @ w.float().T + b.float()
+        ref16 = F.linear(x, w, b)
+        if act == "gelu":
+            truth, ref16 = _gelu_tanh(truth), F.gelu(ref16, approximate="tanh")
+        if res:
+            truth, ref16 = truth + r.float(), ref16 + r
+        name = f"c3_tp{tp}_{what} M{M} N{N} K{K}"
+        _record(name, y, truth, ref16)
+        rows = _sample_rows(M, n=64, seed=tp + i)
+        want = F.linear(x[rows].double().cpu(), w.double().cpu(), b.double().cpu())
+        if act == "gelu":
+            want = oracle.mlp.gelu_tanh(want)
+        if res:
+            want = want + r[rows].double().cpu()
+        _oracle_rows(name, y[rows], want, torch.bfloat16)
+
+
+@pytest.mark.parametrize("tp", [2, 4])
+def test_c3_tensor_parallel_rank_attention(tp):
+    """The H / tp-head attention launch of a tensor-parallel rank at C2 (B 8, S 4096, causal), pre-scaled K as
+    TensorParallelAttention hands it over (strided views of the fused q / k / v result)."""
+    ops = _ops()
+    B, S, d, H = C2["B"], C2["S"], C2["d"], C2["H"]
+    Hl, D = H // tp, d // H
+    qkv, = _c2_inputs(90 + tp, (B, S, 3 * Hl * D))
+    c = D ** -0.5 * 1.4426950408889634
+    q = qkv[..., :Hl * D].view(B, S, Hl, D)
+    kt = qkv[..., Hl * D:2 * Hl * D].view(B, S, Hl, D)  # stands for K~ = K * softmax_scale * log2(e), already rounded
+    v = qkv[..., 2 * Hl * D:].view(B, S, Hl, D)
+    assert ops.fa3_k_prescaled_ok(B, S, S, Hl, D, 3 * Hl * D, 3 * Hl * D)
+    o, lse = ops.fa3_fwd(q, kt, v, causal=True, return_lse=True, k_prescaled=True)
+    # in terms of the plain formula: k = K~ / c with the usual 1 / sqrt(D) scale
+    kf = (kt.float() / c)
+    name = f"c3_tp{tp}_attention B{B} H{Hl} S{S} D{D} causal k_prescaled"
+    truth = _attention_truth(q, kf, v, True)
+    _record(name, o, truth, _attention_ref16(q, kf.to(torch.bfloat16), v, True))
+    _attention_oracle_rows(name, o, lse * 1.0, q, kt, v, True, n=64, seed=tp, softmax_scale=math.log(2.0))
+
+
+@pytest.mark.parametrize("step", ["first", "middle", "diagonal"])
+def test_c4_ring_step_b1_h16_8192x8192(step):
+    """One ring step at BASELINE config 4's per-rank shape (S 65536 over 8 ranks: B 1, H 16, 8192 queries x 8192 keys,
+    head-major [B, H, S, D] as SequenceParallelAttention holds them, pre-scaled K, fp32 (o_acc, lse) carry):
+    first = the local non-causal step of a fresh state, middle = a past shard merged into a carried state,
+    diagonal = the causal local shard.  Checked against the fp32 chain of the merged problem and oracle rows."""
+    ops = _ops()
+    B, H, S, D = 1, 16, 8192, 64
+    c = D ** -0.5 * 1.4426950408889634
+    q, k0, v0, k1, v1 = _c2_inputs(100, (B, S, H, D), (B, S, H, D), (B, S, H, D), (B, S, H, D), (B, S, H, D))
+    kt0 = (k0.float() * c).to(torch.bfloat16)
+    kt1 = (k1.float() * c).to(torch.bfloat16)
+    hm = lambda t: t.permute(0, 2, 1, 3).contiguous()  # head-major storage, handed to the kernel as strided [B, S, H, D] views
+    qh, k0h, v0h, k1h, v1h = (hm(t).permute(0, 2, 1, 3) for t in (q, kt0, v0, kt1, v1))
+    assert ops.fa3_k_prescaled_ok(B, S, S, H, D, D, D, carry=True)
+    o_acc = torch.zeros(B, S, H, D, dtype=torch.float32, device=DEV)
+    lse = torch.full((B, H, S), float("-inf"), device=DEV)
+    out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=DEV)
+    name = f"c4_ring_step {step} B1 H16 8192x8192 D64 k_prescaled carry"
+    if step == "diagonal":
+        ops.fa3_fwd(qh, k0h, v0h, causal=True, q_offset=S, k_offset=S, o_acc=o_acc, lse=lse, carry_in=False, write_out=True,
+                    out=out, k_prescaled=True)
+        kk, vv, causal = kt0, v0, True
+    else:
+        ops.fa3_fwd(qh, k0h, v0h, causal=False, o_acc=o_acc, lse=lse, carry_in=False, write_out=(step == "first"), out=out,
+                    k_prescaled=True)
+        kk, vv, causal = kt0, v0, False
+        if step == "middle":
+            ops.fa3_fwd(qh, k1h, v1h, causal=False, o_acc=o_acc, lse=lse, carry_in=True, write_out=True, out=out,
+                        k_prescaled=True)
+            kk, vv = torch.cat([kt0, kt1], 1), torch.cat([v0, v1], 1)
+    kf = kk.float() / c
+    truth = _attention_truth(q, kf, vv, causal)
+    _record(name, out, truth, _attention_ref16(q, kf.to(torch.bfloat16), vv, causal))
+    assert (o_acc - truth).abs().max().item() < 1.5e-2
+    _attention_oracle_rows(name, out, lse, q, kk, vv, causal, n=64, seed=7, softmax_scale=math.log(2.0))
 
 
 def _attention_truth(q, k, v, causal, chunk_b=1):
@@ -370,9 +503,12 @@ def test_c5_attention_dh80(Sk):
     _attention_oracle_rows(name, o, lse, q, k, v, False, seed=Sk)
 
 
-def test_c5_fused_mlp_gelu():
+@pytest.mark.parametrize("B", [2, 8])
+def test_c5_fused_mlp_gelu(B):
+    """B 8 = bench.py's C5 leg: M 32768 -> blocked d 1280 / I 5120 weights, blocked intermediate (N 1280 = 5 tile
+    columns, K 5120 = 160 K-tiles); B 2 stays on the plain-weight kernels."""
     ops = _ops()
-    B, S, d, I = C5["B"], C5["S"], C5["d"], C5["I"]
+    S, d, I = C5["S"], C5["d"], C5["I"]
     M = B * S
     x, r = _c2_inputs(30, (B, S, d), (B, S, d))
     w1, w2 = _c2_inputs(31, (I, d), (d, I), scale=0.02)
@@ -382,7 +518,8 @@ def test_c5_fused_mlp_gelu():
     y = ops.fused_mlp(x, w1, b1, w2, b2, "gelu", residual=r, **kw)
     truth = _gelu_tanh(x.float().view(M, d) @ w1.float().T + b1.float()) @ w2.float().T + b2.float() + r.float().view(M, d)
     ref16 = (F.linear(F.gelu(F.linear(x, w1, b1), approximate="tanh"), w2, b2) + r).view(M, d)
-    name = "c5_fused_mlp gelu M8192 d1280 I5120 +residual"
+    name = f"c5_fused_mlp gelu M{M} d1280 I5120 +residual"
+    assert blocked == (B == 8)
     _record(name, y.view(M, d), truth, ref16, extra=dict(blocked_weights=bool(blocked)))
     rows = _sample_rows(M, seed=5)
     want = oracle.fused_mlp(x.view(M, d)[rows].cpu(), w1.cpu(), b1.cpu(), w2.cpu(), b2.cpu(), "gelu",
@@ -390,12 +527,14 @@ def test_c5_fused_mlp_gelu():
     _oracle_rows(name, y.view(M, d)[rows], want, torch.bfloat16)
 
 
-def test_c5_cross_block():
+@pytest.mark.parametrize("B,Sk", [(2, 1024 + 77), (8, 4096)])
+def test_c5_cross_block(B, Sk):
     """The C5 block bench.py --workload c5 times: LN -> cross attention (q from x, k / v from a separate context,
-    RingCrossAttention projections) + residual -> LN -> FusedMLP GELU + residual, against the fp32 chain."""
+    RingCrossAttention projections) + residual -> LN -> FusedMLP GELU + residual, against the fp32 chain.
+    (B 8, Sk 4096) is the bench's own shape (blocked weights, blocked hand-overs); (B 2, Sk 1101) a ragged context."""
     from mio.synthetic import CrossBlock
-    B, S, d, H, I = C5["B"], C5["S"], C5["d"], C5["H"], C5["I"]
-    D, Sk = d // H, 1024 + 77
+    S, d, H, I = C5["S"], C5["d"], C5["H"], C5["I"]
+    D = d // H
     torch.manual_seed(1)
     blk = CrossBlock(d, H, I, precision="bf16")
     with torch.no_grad():
@@ -424,7 +563,7 @@ def test_c5_cross_block():
                          f(blk.mlp.mlp.fc2.weight), f(blk.mlp.mlp.fc2.bias))
             return m + a
 
-    _record("c5_cross_block B2 Sq4096 Sk1101 d1280 H16 I5120", y.view(-1, d), chain(torch.float32).view(-1, d),
+    _record(f"c5_cross_block B{B} Sq4096 Sk{Sk} d1280 H16 I5120", y.view(-1, d), chain(torch.float32).view(-1, d),
             chain(torch.bfloat16).view(-1, d))
 
 

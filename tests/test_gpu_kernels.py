@@ -697,3 +697,31 @@ def test_errors_raise_before_launch():
         ops.fused_mlp(xl, w1b, None, w2b, torch.zeros(32, dtype=torch.bfloat16, device=DEV))  # short fc2 bias
     with pytest.raises(ValueError):
         ops.fused_mlp(xl, w1b, None, w2b, None, residual=xl.float())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_mlp_swiglu_blocked_glu_weight(dtype):
+    """SwiGLU on the 256-tile kernels (interleaved gate / up blocked weight, ops.block_weight_glu) at a shape with a ragged
+    last row tile (M = 8200), one missing bias and a residual; against the oracle and the plain dual-B path."""
+    ops = _ops()
+    M, d, I = 8200, 2048, 2048
+    assert ops.fused_mlp_blocked_weight_ok(M, d, I, "swiglu")
+    torch.manual_seed(5)
+    x = torch.randn(1, M, d).to(dtype)
+    r = torch.randn(1, M, d).to(dtype)
+    wu, wg, w2 = ((torch.randn(*s) * 0.03).to(dtype) for s in ((I, d), (I, d), (d, I)))
+    bu, b2 = (torch.randn(I) * 0.1).to(dtype), (torch.randn(d) * 0.1).to(dtype)
+    rows = torch.cat([torch.arange(0, M, 97), torch.tensor([255, 256, 8191, 8192, M - 1])])
+    want = oracle.fused_mlp(x[0, rows], wu, bu, w2, b2, "swiglu", wg, None, residual=r[0, rows])
+    xd, rd, wud, wgd, w2d, bud, b2d = (t.to(DEV) for t in (x, r, wu, wg, w2, bu, b2))
+    y = ops.fused_mlp(xd, wud, bud, w2d, b2d, "swiglu", wgd, None, residual=rd, fc1_blocked=ops.block_weight_glu(wgd, wud),
+                      fc2_blocked=ops.block_weight(w2d))
+    got, refd = y[0, rows.to(DEV)].float().cpu(), want.to(dtype).float()
+    rel = ((got - refd).abs().mean() / refd.abs().mean()).item()
+    assert rel < (2e-3 if dtype == torch.float16 else 5e-3), f"rel_err={rel:.3e}"  # (bars of test_fused_mlp_vs_oracle)
+    y_plain = ops.fused_mlp(xd, wud, bud, w2d, b2d, "swiglu", wgd, None, residual=rd)
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    assert (y.float() - y_plain.float()).abs().max().item() < tol * max(1.0, y_plain.float().abs().max().item())
+    with pytest.raises(ValueError):  # a plain blocked weight is not the interleaved one
+        ops.fused_mlp(xd, wud, bud, w2d, b2d, "swiglu", wgd, None, fc1_blocked=ops.block_weight(wud)[:1],
+                      fc2_blocked=ops.block_weight(w2d))

@@ -27,6 +27,8 @@ def short(name):
         vals = [v for _, v in ints]
         if k in ("gemm4w16_kernel", "gemm4w16p_kernel"):
             return f"{k}<{dt},{ACT.get(vals[0], vals[0])}>"
+        if k == "gemm8w_kernel":  # <T, ACT, RES, VAR>
+            return f"{k}<{dt},{ACT.get(vals[0], vals[0])}{',residual' if vals[1] == '1' else ''}>"
         if k == "gemm_bias_act_kernel":
             return f"{k}<{dt},{ACT.get(vals[-1], vals[-1])}>"
         if k in ("fa3_fwd_kernel", "fa3_fwd2_kernel"):
