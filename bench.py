@@ -441,12 +441,21 @@ def main():
         legs = [(f"tensor_parallel_tp{tp}", 240, (lambda tp=tp: bench_tp(N, tp, B, S, d, H, I, L, dt, steps=max(2, a.steps // 2))))
                 for tp in (2, 4) if N % tp == 0]
         legs.append((f"ring_attention_sp{N}", 420, lambda: bench_ring(N, a.ring_seq, d, H, dt, steps=1 if N < 4 else 2)))
+        try:  # what these legs should show, from the single-GPU kernel times + link rate (tools/scale_model.py)
+            from tools.scale_model import predict
+            model_pred = predict(L=L, B=B, S=S, d=d, H=H, I=I, ring_S=a.ring_seq, measured_single_ms=res["ms_per_step"])
+        except Exception:
+            model_pred = {}
+        res["predicted"] = {k: model_pred[k] for k in (f"dp{N}",) if k in model_pred}
         for name, budget_s, leg in legs:
             dog.arm(name, budget_s)
             try:
                 extra[name] = leg()
             except Exception as ex:
                 extra[name] = {"error": repr(ex)}
+            pk = name if name in model_pred else ("ring_attention_sp8" if name.startswith("ring_attention") and N == 8 else None)
+            if pk and isinstance(extra[name], dict):
+                extra[name]["predicted"] = model_pred[pk]
             dog.disarm()
 
     if rank == 0:

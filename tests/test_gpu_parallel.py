@@ -120,6 +120,33 @@ def _stack_and_input(seed=0):
     return stack, x
 
 
+def _oracle_stack_rows(stack, x, rows):
+    """fp64 oracle of the 2-layer GPT-2-shaped stack (causal) for sampled (batch, position) rows: every layer is evaluated on
+    the whole batch element up to that position (the next layer's keys need all earlier tokens), test-size only."""
+    import oracle
+    F = torch.nn.functional
+    c = lambda t: t.detach().double().cpu()
+    out = []
+    for b in sorted({b for b, _ in rows}):
+        h = c(x[b:b + 1])
+        for blk in stack.h:
+            at = blk.attn
+            H = at.num_attention_heads
+            d = h.shape[-1]
+            a = oracle.layernorm(h, c(blk.ln_1.weight), c(blk.ln_1.bias), blk.ln_1.eps)
+            qkv = F.linear(a, c(at.qkv_proj.weight), c(at.qkv_proj.bias))
+            q, k, v = (t.view(1, -1, H, d // H) for t in qkv.split(d, dim=-1))
+            o = oracle.standard_attention(q, k, v, causal=True).reshape(1, -1, d)
+            h = F.linear(o, c(at.o_proj.weight), c(at.o_proj.bias)) + h
+            m = blk.mlp.mlp
+            h = oracle.fused_mlp(oracle.layernorm(h, c(blk.ln_2.weight), c(blk.ln_2.bias), blk.ln_2.eps), c(m.fc1.weight),
+                                 c(m.fc1.bias), c(m.fc2.weight), c(m.fc2.bias), "gelu", residual=h)
+        h = oracle.layernorm(h, c(stack.ln_f.weight), c(stack.ln_f.bias), stack.ln_f.eps)
+        out.append((b, h[0]))
+    full = dict(out)
+    return torch.stack([full[b][r] for b, r in rows])
+
+
 def _rel(a, b):
     return ((a.float() - b.float()).abs().mean() / b.float().abs().mean()).item()
 
@@ -142,6 +169,11 @@ def _w_sharded_stack(rank, world, mode, zigzag, exchange):
     assert y.shape == ref.shape
     rel = _rel(y, ref)
     assert rel < 4e-3, (mode, zigzag, exchange, rel)
+    rows = [(0, 0), (0, 511), (1, 512), (1, 1023), (0, 777)]  # both ranks' shards, incl. the shard boundary
+    want = _oracle_stack_rows(stack, x, rows)
+    got = torch.stack([y[b, r] for b, r in rows]).double().cpu()
+    orel = ((got - want).abs().mean() / want.abs().mean()).item()
+    assert orel < 6e-3, ("oracle rows", mode, zigzag, exchange, orel)
     if cfg.buffer_reuse and mode == "ring" and exchange == "mesh":
         pools = [a._recv_buffers for a in atts]
         ptrs = [[b.data_ptr() for c in next(iter(p.values())) for b in c] for p in pools]
@@ -180,6 +212,117 @@ def _w_parallel_groups(rank, world):
     assert rel < 4e-3, ("sp2", rel)
 
 
+def _spy_linear():
+    """Record the col_scale argument of every _local.linear call (which branch a module took)."""
+    from mio.parallelism import _local
+    seen, real = [], _local.linear
+
+    def spy(x, weight, bias=None, activation="none", residual=None, out=None, col_scale=None):
+        seen.append(col_scale)
+        return real(x, weight, bias, activation, residual, out, col_scale)
+    _local.linear = spy
+    return seen
+
+
+def _w_kpre_module_branches(rank, world):
+    """The k_prescaled branches of the parallel modules with the REAL kernels at shapes where they are taken
+    (ops.col_scale_ok: the 256-tile GEMM, hidden 1024 = 16 heads of 64): TensorParallelAttention's fused [3n, hidden]
+    projection with col_scale = (n, 2n) + strided q / k / v views + k_prescaled launch, and SequenceParallelAttention's K
+    projection with col_scale + ring of pre-scaled K shards with the (o_acc, lse) carry.  Oracle on sampled rows."""
+    import oracle
+    from mio.parallelism import SequenceParallelAttention, SequenceParallelConfig, TensorParallelAttention, TensorParallelConfig
+    F = torch.nn.functional
+    d, H, dt = 1024, 16, torch.bfloat16
+    D = d // H
+    seen = _spy_linear()
+    g = torch.Generator().manual_seed(7)
+    ws = [(torch.randn(d, d, generator=g) * 0.03).to(dt) for _ in range(4)]
+    bs = [(torch.randn(d, generator=g) * 0.03).to(dt) for _ in range(4)]
+
+    def oracle_rows(x, causal, rows):  # [(b, s)] -> fp64 reference of the block output rows
+        q, k, v = (F.linear(x.double(), w.double(), b.double()) for w, b in zip(ws[:3], bs[:3]))
+        out = []
+        for b, r in rows:
+            n = r + 1 if causal else x.shape[1]
+            o = oracle.standard_attention(q[b:b + 1, r:r + 1].view(1, 1, H, D), k[b:b + 1, :n].view(1, n, H, D),
+                                          v[b:b + 1, :n].view(1, n, H, D), causal=False)
+            out.append(F.linear(o.reshape(d), ws[3].double(), bs[3].double()))
+        return torch.stack(out)
+
+    # --- tensor parallel, tp = 2: per rank n = 512 columns of each of q / k / v
+    B, S = 3, 4096
+    x = torch.randn(B, S, d, generator=g).to(dt)
+    cfg = TensorParallelConfig(world_size=world, tp_size=world, overlap_chunks=2)
+    att = TensorParallelAttention(d, H, cfg, causal=True).to("cuda", dt)
+    pd = d // world
+    for lin, w, b in zip((att.query, att.key, att.value), ws, bs):
+        lin.weight.copy_(w[rank * pd:(rank + 1) * pd]); lin.bias.copy_(b[rank * pd:(rank + 1) * pd])
+    att.output.weight.copy_(ws[3][:, rank * pd:(rank + 1) * pd]); att.output.bias.copy_(bs[3])
+    seen.clear()
+    y = att(x.cuda()).cpu()
+    assert any(c is not None and c[0] == pd and c[1] == 2 * pd for c in seen), ("TensorParallelAttention did not pre-scale K", seen)
+    rows = [(0, 0), (0, 255), (1, 256), (1, 1777), (2, 4095), (2, 3000)]
+    want = oracle_rows(x, True, rows)
+    got = torch.stack([y[b, r] for b, r in rows]).double()
+    rel = ((got - want).abs().mean() / want.abs().mean()).item()
+    assert rel < 6e-3, ("tp kpre", rel)
+
+    # --- sequence parallel ring, sp = 2: 4 x 4096 local tokens per rank
+    B, S = 4, 8192
+    x = torch.randn(B, S, d, generator=g).to(dt)
+    scfg = SequenceParallelConfig(world_size=world, sp_size=world, attention_handling="ring", exchange="mesh", causal=True,
+                                  zigzag=True)
+    sp = SequenceParallelAttention(d, H, scfg, attention_dropout=0.0).to("cuda", dt)
+    for lin, w, b in zip((sp.query, sp.key, sp.value, sp.output), ws, bs):
+        lin.weight.copy_(w); lin.bias.copy_(b)
+    from mio.parallelism.sequence_parallel import zigzag_shard
+    xl = zigzag_shard(x, rank, world, 1).contiguous().cuda()
+    seen.clear()
+    yl = sp(xl).cpu()
+    assert any(c is not None and c[0] == 0 and c[1] == d for c in seen), ("SequenceParallelAttention did not pre-scale K", seen)
+    # local row r of a zig-zag shard: blocks (rank, 2 world - 1 - rank) of S / (2 world) tokens
+    blk = S // (2 * world)
+    pos = lambda r: (rank * blk + r) if r < blk else ((2 * world - 1 - rank) * blk + (r - blk))
+    loc = [(0, 0), (1, blk - 1), (2, blk), (3, 2 * blk - 1), (0, 1234)]
+    want = oracle_rows(x, True, [(b, pos(r)) for b, r in loc])
+    got = torch.stack([yl[b, r] for b, r in loc]).double()
+    rel = ((got - want).abs().mean() / want.abs().mean()).item()
+    assert rel < 4e-3, ("sp ring kpre", rel)
+
+
+def _w_tp2_x_sp2_hip(rank, world):
+    """tensor (2) x sequence (2) on FOUR ranks with the real kernels (reference parallel_utils.py:882-1002): ring attention
+    over the sequence group on this rank's heads, row-parallel out-projection summed over the tensor group == the dense
+    block output for the rank's tokens (oracle)."""
+    import oracle
+    from mio.parallelism import RowParallelLinear, SequenceParallelConfig, TensorParallelConfig
+    from mio.parallelism.sequence_parallel import ring_attention
+    F = torch.nn.functional
+    dt = torch.float16
+    tcfg = TensorParallelConfig(world_size=world, tp_size=2)
+    scfg = SequenceParallelConfig(world_size=world, sp_size=2, tp_size=2, exchange="mesh")
+    tg, sg = tcfg.get_tp_group(), scfg.get_sp_group()
+    tp_r, sp_r = tcfg.tp_rank(), scfg.get_rank_info()[0]
+    assert (tp_r, sp_r) == (rank % 2, rank // 2)
+    torch.manual_seed(0)  # the same tensors on every rank
+    B, S, H, D = 2, 1024, 4, 64
+    d = H * D
+    q, k, v = (torch.randn(B, S, H, D).to(dt) for _ in range(3))
+    wo, bo = (torch.randn(d, d) * 0.05).to(dt), (torch.randn(d) * 0.05).to(dt)
+    dense = F.linear(oracle.standard_attention(q, k, v, causal=True).reshape(B, S, d), wo.double(), bo.double())
+    hs = slice(tp_r * H // 2, (tp_r + 1) * H // 2)
+    ss = slice(sp_r * S // 2, (sp_r + 1) * S // 2)
+    o = ring_attention(q[:, ss, hs].contiguous().cuda(), k[:, ss, hs].contiguous().cuda(), v[:, ss, hs].contiguous().cuda(), sg,
+                       layout="bshd", exchange="mesh", causal=True, recv_buffers={})
+    row = RowParallelLinear(d, d, True, tcfg, input_is_parallel=True).to("cuda", dt)
+    row.weight.copy_(wo[:, tp_r * d // 2:(tp_r + 1) * d // 2])
+    row.bias.copy_(bo)
+    y = row(o.reshape(B, S // 2, d // 2)).cpu().double()
+    want = dense[:, ss]
+    rel = ((y - want).abs().mean() / want.abs().mean()).item()
+    assert rel < 2e-3, rel
+
+
 def _w_bench_extras(rank, world):
     """The exact code bench.py runs for its multi-GPU 'extra' block, at a small size (plumbing check)."""
     from tools.bench_parallel import bench_ring, bench_tp
@@ -212,6 +355,14 @@ def test_tensor_parallel_hip_ws2():
 @pytest.mark.parametrize("mode,zigzag,exchange", [("ring", False, "mesh"), ("ring", True, "ring"), ("full", False, "ring")])
 def test_sequence_sharded_stack_hip_ws2(mode, zigzag, exchange):
     _run("_w_sharded_stack", 2, (mode, zigzag, exchange))
+
+
+def test_k_prescaled_module_branches_hip_ws2():
+    _run("_w_kpre_module_branches", 2)
+
+
+def test_tensor2_x_sequence2_hip_ws4():
+    _run("_w_tp2_x_sp2_hip", 4)
 
 
 def test_parallel_groups_hip_ws2():
