@@ -224,7 +224,7 @@ def _spy_linear():
     return seen
 
 
-def _w_kpre_module_branches(rank, world):
+def _w_kpre_module_branches(rank, world, which):
     """The k_prescaled branches of the parallel modules with the REAL kernels at shapes where they are taken
     (ops.col_scale_ok: the 256-tile GEMM, hidden 1024 = 16 heads of 64): TensorParallelAttention's fused [3n, hidden]
     projection with col_scale = (n, 2n) + strided q / k / v views + k_prescaled launch, and SequenceParallelAttention's K
@@ -249,6 +249,8 @@ def _w_kpre_module_branches(rank, world):
             out.append(F.linear(o.reshape(d), ws[3].double(), bs[3].double()))
         return torch.stack(out)
 
+    if which == "sp":
+        return _kpre_sp_part(rank, world, d, H, dt, g, ws, bs, seen, oracle_rows)
     # --- tensor parallel, tp = 2: per rank n = 512 columns of each of q / k / v
     B, S = 3, 4096
     x = torch.randn(B, S, d, generator=g).to(dt)
@@ -267,6 +269,10 @@ def _w_kpre_module_branches(rank, world):
     rel = ((got - want).abs().mean() / want.abs().mean()).item()
     assert rel < 6e-3, ("tp kpre", rel)
 
+
+
+def _kpre_sp_part(rank, world, d, H, dt, g, ws, bs, seen, oracle_rows):
+    from mio.parallelism import SequenceParallelAttention, SequenceParallelConfig
     # --- sequence parallel ring, sp = 2: 4 x 4096 local tokens per rank
     B, S = 4, 8192
     x = torch.randn(B, S, d, generator=g).to(dt)
@@ -357,8 +363,9 @@ def test_sequence_sharded_stack_hip_ws2(mode, zigzag, exchange):
     _run("_w_sharded_stack", 2, (mode, zigzag, exchange))
 
 
-def test_k_prescaled_module_branches_hip_ws2():
-    _run("_w_kpre_module_branches", 2)
+@pytest.mark.parametrize("which", ["tp", "sp"])
+def test_k_prescaled_module_branches_hip_ws2(which):
+    _run("_w_kpre_module_branches", 2, (which,))
 
 
 def test_tensor2_x_sequence2_hip_ws4():

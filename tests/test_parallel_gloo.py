@@ -156,6 +156,30 @@ def _w_ring(rank, world, exchange, causal, zigzag, layout):
     assert (out.double() - ref_loc).abs().max() < 1e-5, (exchange, causal, zigzag, layout)
 
 
+def _w_ring_coalesced_work(rank, world):
+    """RCCL returns ONE work for a grouped batch_isend_irecv; gloo one per transfer.  Force the coalesced shape under gloo
+    (a wrapper whose single work waits for all of them) so that mesh_exchange_start's `per_op = False` branch -- the first
+    wait_chunk covers every peer -- runs the whole ring_attention schedule (mesh, causal zig-zag and plain)."""
+    import torch.distributed as d
+    real = d.batch_isend_irecv
+
+    class _All:
+        def __init__(self, ws):
+            self.ws = ws
+
+        def wait(self):
+            for w in self.ws:
+                w.wait()
+            self.ws = []
+
+    d.batch_isend_irecv = lambda ops: [_All(real(ops))]
+    try:
+        _w_ring(rank, world, "mesh", True, True, "bshd")
+        _w_ring(rank, world, "mesh", False, False, "bhsd")
+    finally:
+        d.batch_isend_irecv = real
+
+
 def _w_ring_mask(rank, world):
     import oracle
     from mio.parallelism.sequence_parallel import ring_attention
@@ -306,6 +330,10 @@ def test_ring_attention_ws2(exchange, causal, zigzag, layout):
 @pytest.mark.parametrize("exchange,causal,zigzag", [("ring", True, True), ("mesh", False, False), ("mesh", True, False)])
 def test_ring_attention_ws4(exchange, causal, zigzag):
     _run("_w_ring", 4, (exchange, causal, zigzag, "bhsd"))
+
+
+def test_ring_attention_mesh_coalesced_work_ws4():
+    _run("_w_ring_coalesced_work", world=4)
 
 
 def test_ring_attention_additive_mask_ws2():
