@@ -142,11 +142,15 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
   // last iterations of the first, and its Q rows in front of the first pass' epilogue.
   // static priority for the half of the waves that leads (waves 0..3 run half an iteration ahead): -1 % measured; the other
   // half at priority 1 instead: +3 %.  (Diagnostic library: bits 4 / 5 of xcd_remap = none / the other half.)
+#ifdef MIO_DIAG
   if (p.xcd_remap & 32) {
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
   } else if (!(p.xcd_remap & 16)) {
     if (wave < 4) __builtin_amdgcn_s_setprio(1);
   }
+#else
+  if (wave < 4) __builtin_amdgcn_s_setprio(1);
+#endif
   int tbase = 0, vnext = 0, vseen = 0;
   X8 qf_next[NQG][NDS];
   load_q(0, qf_next);
@@ -473,15 +477,57 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       st_all[6] += n_tiles;
     }
 
-    // ---- epilogue: lane (c16, g) holds O[query qrow[qg]][d = 16 dt + 4 g + i]: one 8-byte store per (dt, qg)
+    // ---- epilogue: lane (c16, g) holds O[query qrow[qg]][d = 16 dt + 4 g + i], 8 bytes per (dt, qg).  The two query groups
+    // are exchanged between lane rows g and g ^ 1 (v_permlane16_swap per dword): even rows end up with 16 contiguous bytes
+    // (d = 16 dt + 4 g .. + 7) of query group 0, odd rows with 16 bytes (d = 16 dt + 4 (g - 1) ..) of query group 1 -- half the
+    // store instructions for the same bytes (the store tail is issue-bound: 73 cycles per wave-instruction).
+    float inv2[NQG];
 #pragma unroll
     for (int qg = 0; qg < NQG; ++qg) {
       const float l_tot = L[qg][0];
-      const float inv = (l_tot > 0.f) ? fast_rcp(l_tot) : 0.f;
+      inv2[qg] = (l_tot > 0.f) ? fast_rcp(l_tot) : 0.f;
       if (q_ok[qg] && p.lse != nullptr && g == 0) {
         const float lse = (l_tot > 0.f) ? (ref[qg] + fast_log2(l_tot)) * FA_LN2 : -INFINITY;
         p.lse[((int64_t)b * p.H + head) * p.Sq + qrow[qg]] = lse;
       }
+    }
+    bool wide = (NQG == 2 && !CARRY);
+#ifdef MIO_DIAG
+    wide = wide && !(p.xcd_remap & 64);  // (A/B: bit 6 keeps the 8-byte stores)
+#endif
+    if (wide) {
+      const int mq = g & 1;                       // the query group this lane stores after the exchange
+      const int dofs = 4 * (g & ~1);              // first of its 8 head-dim columns inside a 16-column tile
+      const bool ok = q_ok[mq];
+      const int qr = ok ? qrow[mq] : 0;
+      u32x4_t keep[NDT];
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        uint32_t a0 = pack2<T>(O[dt][0][0] * inv2[0], O[dt][0][1] * inv2[0]), a1 = pack2<T>(O[dt][0][2] * inv2[0], O[dt][0][3] * inv2[0]);
+        uint32_t b0 = pack2<T>(O[dt][1][0] * inv2[1], O[dt][1][1] * inv2[1]), b1 = pack2<T>(O[dt][1][2] * inv2[1], O[dt][1][3] * inv2[1]);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+        // even rows: {own a0, own a1, a0 / a1 of row g + 1}; odd rows: {b0 / b1 of row g - 1, own b0, own b1}
+        const u32x4_t w = {s0[0], s1[0], s0[1], s1[1]};
+        keep[dt] = w;
+        const int d0 = 16 * dt + dofs;
+        if constexpr (OBLK) {
+          const int64_t m = (int64_t)b * p.Sq + qr;
+          char* ob = (char*)p.o + (((m >> 8) * ((p.H * p.D) >> 5)) << 14) + ((m & 255) << 6);
+          const int c = head * p.D + d0;
+          if (ok && d0 < p.D) *(u32x4_t*)(ob + ((int64_t)(c >> 5) << 14) + ((c & 31) << 1)) = w;
+        } else {
+          T* op = (T*)p.o + b * p.os_b + head * p.os_h + (int64_t)qr * p.os_s;
+          if (ok && d0 < p.D) *(u32x4_t*)(op + d0) = w;
+        }
+      }
+      // the stored registers stay untouched until the stores have fetched them (gemm8w_kernel.h: store data must outlive ...)
+      if constexpr (NDT == 4) asm volatile("s_nop 15\n\ts_nop 15" : : "v"(keep[0]), "v"(keep[1]), "v"(keep[2]), "v"(keep[3]) : "memory");
+      else if constexpr (NDT == 2) asm volatile("s_nop 15\n\ts_nop 15" : : "v"(keep[0]), "v"(keep[1]) : "memory");
+    } else {
+#pragma unroll
+    for (int qg = 0; qg < NQG; ++qg) {
+      const float inv = inv2[qg];
       if (!CARRY || p.o != nullptr) {
         if constexpr (OBLK) {
           // element (m, c) of the [B*Sq, H*D] matrix in the GEMMs' blocked activation layout:
@@ -516,6 +562,7 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
         }
       }
     }
+    }  // (the 8-byte form: ring carry launches, which also write the fp32 state)
     if constexpr (STAMP) st_all[11] += __builtin_amdgcn_s_memtime();
   }  // pass
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be writing LDS when the wave ends

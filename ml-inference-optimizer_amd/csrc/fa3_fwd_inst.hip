@@ -170,7 +170,7 @@ static int launch_five(FaDev p, hipStream_t stream) {
   void (*kern)(const FaDev) = fa3_fwd5_kernel<FaT, CAUSAL, false, 0, CARRY, OBLK>;
 #if defined(MIO_DIAG) && FA_TYPE_ID == 0
   if constexpr (!CARRY && !OBLK) {
-  p.xcd_remap |= (mio_dbg_get(3) & 3) << 4;  // wave-priority probe (tools/fa5_ablate.py)
+  p.xcd_remap |= (mio_dbg_get(3) & 7) << 4;  // wave-priority probe (tools/fa5_ablate.py)
   static const char* dbg_ptr = std::getenv("MIO_FA_DBG_PTR");  // in-kernel phase stamps (tools/fa5_stamps.py)
   if (dbg_ptr != nullptr) {
     auto kd = fa3_fwd5_kernel<FaT, CAUSAL, true>;

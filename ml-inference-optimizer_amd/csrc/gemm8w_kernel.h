@@ -97,7 +97,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
   };
   auto setup = [&](int tile) {
     int tm, tn;
-    gemm_tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
+    gemm_tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn, p.group_m > 0 ? p.group_m : 4);  // 4: measured end to end
     m0 = (int64_t)tm * 256;
     n0 = tn * BN;
     mrem = p.M - m0;

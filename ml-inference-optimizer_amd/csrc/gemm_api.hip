@@ -57,7 +57,7 @@ extern "C" int mio_gemm_bias_act(const void* x, const void* w, const void* bias,
   p.x_blk = p.y_blk = 0;
   p.w_blk = 0;
   p.dbg = nullptr;
-  p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f;
+  p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f; p.group_m = 0;
   return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
 }
 
@@ -98,7 +98,7 @@ static int fused_mlp_impl(const void* x, const void* w1, const void* b1, const v
     p.tiles_m = p.tiles_n = 0;
     p.x_blk = xblk; p.y_blk = 1; p.w_blk = (act == MIO_ACT_SWIGLU) ? 2 : wblk;  // 2: gate / up rows interleaved per wave
     p.dbg = nullptr;
-    p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f;
+    p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f; p.group_m = 0;
     int rc = gemm_dispatch(p, act, dtype, (hipStream_t)stream);
     if (rc != 0) return rc;
     p.x = workspace; p.w = w2; p.bias = b2; p.bias_g = nullptr; p.res = residual; p.y = y;
@@ -188,7 +188,7 @@ extern "C" int mio_gemm_bias_act_bw(const void* x, const void* wb, const void* b
   p.tiles_m = p.tiles_n = 0;
   p.x_blk = x_blocked ? 1 : 0; p.y_blk = 0; p.w_blk = 1;
   p.dbg = nullptr;
-  p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f;
+  p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f; p.group_m = 0;
   return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
 }
 
@@ -220,7 +220,7 @@ extern "C" int mio_gemm_bias_act_bw_cs(const void* x, const void* wb, const void
   p.tiles_m = p.tiles_n = 0;
   p.x_blk = x_blocked ? 1 : 0; p.y_blk = 0; p.w_blk = 1;
   p.dbg = nullptr;
-  p.cs_lo = cs_lo; p.cs_hi = cs_hi; p.cs_val = cs_val;
+  p.cs_lo = cs_lo; p.cs_hi = cs_hi; p.cs_val = cs_val; p.group_m = 0;
   return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
 }
 

@@ -196,6 +196,9 @@ int gemm_launch<GT>(GemmDev p, int act, hipStream_t stream) {
 #ifdef MIO_DIAG
   static const char* dbg_ptr = std::getenv("MIO_GEMM_DBG_PTR");
   if (dbg_ptr != nullptr) p.dbg = (unsigned long long*)std::strtoull(dbg_ptr, nullptr, 0);
+  static const char* gm = std::getenv("MIO_GEMM_GROUP_M");  // tile-order sweep (tools/dbg)
+  if (gm != nullptr) p.group_m = std::atoi(gm);
+  if (mio_dbg_get(5) > 0) p.group_m = mio_dbg_get(5);
 #endif
   switch (act) {
     case MIO_ACT_NONE: return launch_act<MIO_ACT_NONE>(p, stream);

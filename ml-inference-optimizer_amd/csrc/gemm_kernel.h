@@ -43,6 +43,7 @@ struct GemmDev {
   // (mio_fa3_fwd k_prescaled).  cs_lo >= cs_hi: off.
   int cs_lo, cs_hi;
   float cs_val;
+  int group_m;  // row tiles that share each weight tile inside an XCD's run of tiles (0: the default 8)
 };
 
 int mio_gemm_impl();  // MIO_GEMM_IMPL override (0 = default dispatch); defined in gemm_api.hip
@@ -93,12 +94,11 @@ __device__ __forceinline__ f32x2_t gemm_act2(f32x2_t v) {
 
 // XCD-aware, grouped tile order: consecutive ids (round-robin over the 8 XCDs) are folded so each
 // XCD walks a contiguous run of tiles; inside a run GROUP_M row-tiles share each weight tile.
-__device__ __forceinline__ void gemm_tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+__device__ __forceinline__ void gemm_tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M = 8) {
   const int nwg = tiles_m * tiles_n;
   const int q = nwg >> 3, rr = nwg & 7;
   const int xcd = id & 7, idx = id >> 3;
   const int pid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-  constexpr int GROUP_M = 8;
   const int per_group = GROUP_M * tiles_n;
   const int g = pid / per_group;
   const int first_m = g * GROUP_M;
