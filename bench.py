@@ -181,6 +181,25 @@ def decode_leg(dt):
             "tokens_per_s": Bd / (ms * 1e-3)}
 
 
+def attention_functional_leg(dt):
+    """The reference's functional entry point, triton_flash_attention(q, k, v, causal=True) (flash_attention_kernels.py:1150-1358),
+    at the C2 attention shape with plain (not pre-scaled) K: fa3_fwd5_kernel's KPRE = false form."""
+    import torch
+    from mio import ops
+
+    B, S, H, D = 8, 4096, 16, 64
+    torch.manual_seed(5)
+    q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=dt) for _ in range(3))
+    out = {}
+    for causal in (True, False):
+        ms = _events_ms(lambda: ops.flash_attention(q, k, v, causal=causal), 10)
+        flops = (2.0 * B * S * (S + 1) if causal else 4.0 * B * S * S) * H * D
+        out["causal" if causal else "non_causal"] = {"ms": ms, "tflops": flops / (ms * 1e-3) / 1e12,
+                                                     "mfma_roofline_frac": flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
+    out["workload"] = f"ops.flash_attention(q, k, v) B={B} S={S} H={H} D={D}, K not pre-scaled"
+    return out
+
+
 def swiglu_leg(dt):
     """FusedMLP-SwiGLU at the C2 shape (M 32768, d 1024, I 4096; 6 M d I FLOPs): the gated form of gemm8w_kernel on the
     interleaved gate / up blocked weight + fc2 with bias and residual (reference mlp_kernels.py:417-641)."""
@@ -414,7 +433,8 @@ def main():
         del model
         torch.cuda.empty_cache()
         extra = res.setdefault("extra", {})
-        for name, leg in (("decode_roofline", lambda: decode_leg(dt)), ("c5", lambda: c5_leg(dt)), ("swiglu", lambda: swiglu_leg(dt))):
+        for name, leg in (("decode_roofline", lambda: decode_leg(dt)), ("c5", lambda: c5_leg(dt)), ("swiglu", lambda: swiglu_leg(dt)),
+                          ("attention_functional", lambda: attention_functional_leg(dt))):
             try:
                 extra[name] = leg()
             except Exception as ex:

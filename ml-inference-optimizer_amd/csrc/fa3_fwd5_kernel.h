@@ -43,7 +43,11 @@ constexpr int FA5_SMEM = FA5_STAGES * FA4_STAGE;
 
 // CARRY: the ring form -- (o_acc fp32 [B, Sq, H, D], lse) carried in (p.carry_in) and written back; p.o may be null.
 // OBLK: the 16-bit output goes to the GEMMs' blocked activation layout (FaDev::o_blk launches; not with CARRY).
-template <typename T, bool CAUSAL, bool STAMP = false, int ABL = 0, bool CARRY = false, bool OBLK = false>  // ABL: timing-only ablations (diagnostic build)
+// KPRE = false: K arrives as it is (the reference's functional entry point, triton_flash_attention(q, k, v)): the scores
+// and the running reference stay in RAW units (q . k), the C operand subtracts the raw reference, and softmax_scale * log2(e)
+// is applied in fp32 on the way into exp2 (one v_pk_mul per two scores: 16 vector instructions per wave-tile more than the
+// pre-scaled form, no extra rounding of Q or K).
+template <typename T, bool CAUSAL, bool STAMP = false, int ABL = 0, bool CARRY = false, bool OBLK = false, bool KPRE = true>  // ABL: timing-only ablations (diagnostic build)
 __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
   using X8 = typename DT<T>::x8;
   using X4 = typename DT<T>::x4;
@@ -234,6 +238,7 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
     }
     // per query group: ref = the reference subtracted through the C operand (running maximum at the last move + margin; 0
     // while the row is fresh), nref4 = -ref in all four registers; orw = OR of the tile's packed P words
+    const float cs = KPRE ? 1.f : p.scale_log2e, ics = KPRE ? 1.f : 1.f / p.scale_log2e;  // score units -> base-2 exponent
     float ref[NQG] = {0.f, 0.f};
     bool fresh[NQG] = {true, true};
     bool fresh_any = true;
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
         for (int qg = 0; qg < NQG; ++qg) {
           const float lse_in = q_ok[qg] ? p.lse[((int64_t)b * p.H + head) * p.Sq + qrow[qg]] : -INFINITY;
           if (lse_in != -INFINITY) {
-            ref[qg] = lse_in * FA_LOG2E;
+            ref[qg] = lse_in * FA_LOG2E * ics;
             fresh[qg] = false;
             L[qg] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
             const float* oa = p.o_acc + (((int64_t)b * p.Sq + qrow[qg]) * p.H + head) * p.D;
@@ -284,10 +289,16 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
     // one exp / convert unit: the 4 scores of (key tile kt, query group qg) -> two words of P^T fragment (kt / 2, qg)
     auto exp_unit = [&](auto CB_, auto U_) __attribute__((always_inline)) {
       constexpr int cb = decltype(CB_)::value, u = decltype(U_)::value, kt = u >> 1, qg = u & 1;
-      const float e0 = fast_exp2(S[cb][kt][qg][0]);
-      const float e1 = fast_exp2(S[cb][kt][qg][1]);
-      const float e2 = fast_exp2(S[cb][kt][qg][2]);
-      const float e3 = fast_exp2(S[cb][kt][qg][3]);
+      float x0 = S[cb][kt][qg][0], x1 = S[cb][kt][qg][1], x2 = S[cb][kt][qg][2], x3 = S[cb][kt][qg][3];
+      if constexpr (!KPRE) {
+        const f32x2_t c2 = {cs, cs};
+        const f32x2_t a = (f32x2_t){x0, x1} * c2, bb = (f32x2_t){x2, x3} * c2;
+        x0 = a[0]; x1 = a[1]; x2 = bb[0]; x3 = bb[1];
+      }
+      const float e0 = fast_exp2(x0);
+      const float e1 = fast_exp2(x1);
+      const float e2 = fast_exp2(x2);
+      const float e3 = fast_exp2(x3);
       const uint32_t w0 = pack2<T>(e0, e1), w1 = pack2<T>(e2, e3);
       orw |= w0 | w1;
       asm volatile("" ::"v"(w0), "v"(w1));  // a use in THIS step: keeps the work from sinking to its consumer in phase 2
@@ -364,9 +375,9 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
           for (int i = 0; i < 4; ++i) mxl = fmaxf(mxl, S[cb][kt][qg][i]);
         mxl = fmaxf(mxl, __shfl_xor(mxl, 16, 64));  // the four lanes c16 + 16 g of a query hold its 64 keys
         const float mxr = fmaxf(mxl, __shfl_xor(mxl, 32, 64));
-        const bool need = fresh[qg] ? (mxr != -INFINITY) : (mxr >= 1.0f);
-        const float delta = need ? mxr + Fa4Margin<T>::value : 0.f;
-        const float alpha = (need && !fresh[qg]) ? fast_exp2(-delta) : 1.f;
+        const bool need = fresh[qg] ? (mxr != -INFINITY) : (mxr >= ics);  // some P >= 2
+        const float delta = need ? mxr + Fa4Margin<T>::value * ics : 0.f;
+        const float alpha = (need && !fresh[qg]) ? fast_exp2(-delta * cs) : 1.f;
         if (need) fresh[qg] = false;
         ref[qg] += delta;
 #pragma unroll
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(512) void fa3_fwd5_kernel(const FaDev p) {
       const float l_tot = L[qg][0];
       inv2[qg] = (l_tot > 0.f) ? fast_rcp(l_tot) : 0.f;
       if (q_ok[qg] && p.lse != nullptr && g == 0) {
-        const float lse = (l_tot > 0.f) ? (ref[qg] + fast_log2(l_tot)) * FA_LN2 : -INFINITY;
+        const float lse = (l_tot > 0.f) ? (ref[qg] * cs + fast_log2(l_tot)) * FA_LN2 : -INFINITY;
         p.lse[((int64_t)b * p.H + head) * p.Sq + qrow[qg]] = lse;
       }
     }

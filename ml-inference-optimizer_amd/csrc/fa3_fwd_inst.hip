@@ -117,8 +117,9 @@ static int launch_three(FaDev p, hipStream_t stream) {
   return 0;
 }
 
-// fourth structure (two waves per SIMD, 8 waves x 32 query rows): head dim <= 64, no user mask, plain output
-#if FA_D == 64
+// fourth structure (two waves per SIMD, 8 waves x 32 query rows, 32x32x16 tiles): head dim <= 64, no user mask, plain output.
+// Diagnostic library only since round 3: fa3_fwd5_kernel takes every launch it used to (with and without pre-scaled K).
+#if FA_D == 64 && defined(MIO_DIAG)
 template <bool CAUSAL, bool KPRE = false>
 static int launch_four(FaDev p, hipStream_t stream) {
   p.nqblk = (p.Sq + FA4_BM - 1) / FA4_BM;
@@ -162,14 +163,14 @@ static int launch_four(FaDev p, hipStream_t stream) {
 
 // fifth structure (fa3_fwd4's skeleton on 16x16x32 MFMA tiles): k_prescaled launches, head dim <= 64
 #if FA_D == 64
-template <bool CAUSAL, bool CARRY = false, bool OBLK = false>
+template <bool CAUSAL, bool CARRY = false, bool OBLK = false, bool KPRE = true>
 static int launch_five(FaDev p, hipStream_t stream) {
   p.nqblk = (p.Sq + FA4_BM - 1) / FA4_BM;
   p.qgrid = CAUSAL ? (p.nqblk + 1) / 2 : p.nqblk;
   const int grid = p.qgrid * p.B * p.H;
-  void (*kern)(const FaDev) = fa3_fwd5_kernel<FaT, CAUSAL, false, 0, CARRY, OBLK>;
+  void (*kern)(const FaDev) = fa3_fwd5_kernel<FaT, CAUSAL, false, 0, CARRY, OBLK, KPRE>;
 #if defined(MIO_DIAG) && FA_TYPE_ID == 0
-  if constexpr (!CARRY && !OBLK) {
+  if constexpr (!CARRY && !OBLK && KPRE) {
   p.xcd_remap |= (mio_dbg_get(3) & 7) << 4;  // wave-priority probe (tools/fa5_ablate.py)
   static const char* dbg_ptr = std::getenv("MIO_FA_DBG_PTR");  // in-kernel phase stamps (tools/fa5_stamps.py)
   if (dbg_ptr != nullptr) {
@@ -254,14 +255,18 @@ int fa3_launch<FaT, FA_D>(const FaDev& p, int causal, int mask_kind, hipStream_t
       if (which == 4) return causal ? launch_four<true, true>(p, stream) : launch_four<false, true>(p, stream);
 #endif
     }
-    bool four = plain && causal && fa_impl() == 0 && !p.k_prescaled;
+    // plain K (the functional entry point and every module that does not own the K projection's epilogue): the same
+    // structure with the scale applied in fp32 on the way into exp2
+    if (!p.k_prescaled && plain && fa_impl() == 0
 #ifdef MIO_DIAG
-    if (mio_dbg_get(1) == 3) four = false;
-    if (plain && (fa_impl() == 4 || mio_dbg_get(1) == 4)) four = true;
+        && mio_dbg_get(1) == 0
 #endif
-    if (four && causal) return launch_four<true>(p, stream);
+    )
+      return causal ? launch_five<true, false, false, false>(p, stream) : launch_five<false, false, false, false>(p, stream);
 #ifdef MIO_DIAG
-    if (four) return launch_four<false>(p, stream);
+    bool four = false;
+    if (plain && (fa_impl() == 4 || mio_dbg_get(1) == 4)) four = true;
+    if (four) return causal ? launch_four<true>(p, stream) : launch_four<false>(p, stream);
 #endif
   }
 #endif

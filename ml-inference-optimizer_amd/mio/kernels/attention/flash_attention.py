@@ -160,9 +160,27 @@ class FlashAttentionLayer(_AttentionBase):
             out = self._paged(linear(x, self.q_proj, c, dt), B, S, dt, kwargs, "FlashAttentionLayer", r)
             return out if in_dtype == dt else out.to(in_dtype)
         q = linear(x, self.q_proj, c, dt).view(B, S, self.num_attention_heads, self.head_dim)
-        k = linear(x, self.k_proj, c, dt).view(B, S, self.num_kv_heads, self.head_dim)
+        # as FlashSelfAttention: where both kernels allow it the K projection's epilogue hands over K * softmax_scale * log2(e)
+        # (scaled in fp32, rounded once) and the attention launch is told so (ops.fa3_fwd k_prescaled)
+        cfg = self.config
+        kv_dim = self.num_kv_heads * self.head_dim
+        kpre = (attention_mask is None and not cfg.normalize_query and not cfg.return_softmax and kv_dim % 128 == 0
+                and self.k_proj.in_features % 32 == 0
+                and ops.fa3_k_prescaled_ok(B, S, S, self.num_attention_heads, self.head_dim, kv_dim, kv_dim)
+                and ops.blocked_weight_ok(B * S, kv_dim, self.k_proj.in_features)
+                and ops.col_scale_ok(B * S, kv_dim, self.k_proj.in_features))
+        cs = None
+        if kpre:
+            sc = cfg.softmax_scale if cfg.softmax_scale is not None else 1.0 / math.sqrt(self.head_dim)
+            cs = (0, kv_dim, sc * 1.4426950408889634)
+        k = linear(x, self.k_proj, c, dt, col_scale=cs).view(B, S, self.num_kv_heads, self.head_dim)
         v = linear(x, self.v_proj, c, dt).view(B, S, self.num_kv_heads, self.head_dim)
-        ctx = self._attend(q, k, v, attention_mask).view(B, S, self.hidden_size)
+        if kpre:
+            if self.training and cfg.dropout_p > 0.0:
+                raise NotImplementedError("attention dropout (training) is not supported by the inference kernel")
+            ctx = ops.fa3_fwd(q, k, v, causal=cfg.causal, k_prescaled=True).view(B, S, self.hidden_size)
+        else:
+            ctx = self._attend(q, k, v, attention_mask).view(B, S, self.hidden_size)
         out = linear(ctx, self.o_proj, c, dt, residual=r)
         return out if in_dtype == dt else out.to(in_dtype)
 

@@ -423,6 +423,42 @@ def test_c2_attention_b8_h16_s4096_causal_k_prescaled():
     del k32, q32, v32, qkv32
 
 
+def test_c2_attention_layer_separate_projections():
+    """FlashAttentionLayer (reference flash_attention.py:474-659: separate q / k / v / o projections) at C2: the K projection's
+    epilogue pre-scales K (col_scale over all of its columns) and the attention launch is the k_prescaled fa3_fwd5 one."""
+    from mio.kernels.attention import FlashAttentionConfig, FlashAttentionLayer
+    B, S, d, H = C2["B"], C2["S"], C2["d"], C2["H"]
+    D = d // H
+    torch.manual_seed(3)
+    mod = FlashAttentionLayer(d, H, FlashAttentionConfig(causal=True, precision="bf16"))
+    with torch.no_grad():
+        for lin in (mod.q_proj, mod.k_proj, mod.v_proj, mod.o_proj):
+            lin.weight.copy_(torch.randn(lin.weight.shape) * 0.03)
+            lin.bias.copy_(torch.randn(lin.bias.shape) * 0.03)
+    mod = mod.to(device=DEV, dtype=torch.bfloat16).eval()
+    x, r = _c2_inputs(33, (B, S, d), (B, S, d))
+    seen = []
+    ops = _ops()
+    real = ops.fa3_fwd
+    ops.fa3_fwd = lambda *a, **kw: (seen.append(kw.get("k_prescaled", False)), real(*a, **kw))[1]
+    try:
+        with torch.no_grad():
+            y = mod(x, residual=r)
+    finally:
+        ops.fa3_fwd = real
+    assert seen == [True], seen
+
+    def chain(dt):
+        f = lambda t: t.to(dt)
+        with torch.no_grad():
+            q, k, v = (F.linear(f(x), f(l.weight), f(l.bias)).view(B, S, H, D) for l in (mod.q_proj, mod.k_proj, mod.v_proj))
+            c = (_attention_truth(q, k, v, True) if dt == torch.float32 else _attention_ref16(q, k, v, True)).to(dt)
+            return F.linear(c.view(B, S, d), f(mod.o_proj.weight), f(mod.o_proj.bias)) + f(r)
+
+    _record("c2_attention_layer B8 S4096 d1024 H16 (separate projections, K pre-scaled)", y.view(-1, d),
+            chain(torch.float32).view(-1, d), chain(torch.bfloat16).view(-1, d))
+
+
 def test_c2_block_b8_s4096():
     """One full pre-LN block of the benchmark stack (LN -> QKV -> causal attention -> out-proj + residual -> LN ->
     fc1 + GELU -> fc2 + residual) at B 8, S 4096 against the unrounded fp32 chain, the reference's bf16 chain, and

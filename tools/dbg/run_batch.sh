@@ -1,4 +1,3 @@
-python tools/dbg/fa5_store_ab.py 2>&1 | tail -5
-python -m pytest tests -m gpu -x -q > gpurun_out/r3_gputest3.log 2>&1; tail -4 gpurun_out/r3_gputest3.log
-for i in 1 2; do python bench.py --no-extra --steps 20 --warmup 3 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step', round(d['ms_per_step'],3))"; done
+python -m pytest tests -m gpu -x -q > gpurun_out/r3_gputest4.log 2>&1; tail -6 gpurun_out/r3_gputest4.log
+python bench.py > gpurun_out/r3_bench4.json 2> gpurun_out/r3_bench4.err; python -c "
+import json; d=json.load(open('gpurun_out/r3_bench4.json')); print(d['value'], d['ms_per_step'], d['mfma_roofline_frac_end_to_end']); print(json.dumps(d['kernels_per_layer'])); print(d['extra']['c5']); print(d['extra']['swiglu']); print(d['extra']['attention_functional'])"
