@@ -60,11 +60,15 @@ static inline int dec_nsplit_rows(int B, int max_ctx) {
 // Picked for B >= 16: at B 8 (128 MiB of cache, Infinity-Cache resident between launches) the per-head kernel's 512
 // small workgroups run 28 us against 40-46 us here; from B 32 on (streams from HBM) the whole-row reads win:
 // B 64 H 16 D 64 187 -> 183 us (5.87 TB/s), B 256 6.06 TB/s (tools/dbg/dec_rows_sweep.py).
-static inline bool dec_rows_ok(int B, int H, int Hkv, int q_len, int D) {
-  if (B < 16) return false;
+static inline bool dec_rows_ok(int B, int H, int Hkv, int q_len, int D, int max_ctx) {
+  // a cache that fits the 256 MiB Infinity Cache between steps (B 8 at ctx 4096: 128 MiB) is read faster by the per-head
+  // kernel's many small workgroups (28 vs 40-46 us); one that streams from HBM goes through whole token rows from B 8 on
+  // (round 3, B 8 x ctx 32768: 5.49 vs 5.42 TB/s; B 4 x ctx 65536: 5.02 vs 5.41 -- too few sequences per split column)
+  const double kv_bytes = 4.0 * B * (double)max_ctx * Hkv * D;
+  if (B < 16 && (B < 8 || kv_bytes <= 200.0 * 1048576.0)) return false;
   if (D != 64 && D != 128) return false;
   const int cpt = Hkv * (D / 8), qn = (H / Hkv) * q_len;
-  return cpt >= 16 && cpt <= 256 && (cpt & (cpt - 1)) == 0 && (qn == 1 || qn == 2 || qn == 4);
+  return cpt >= 16 && cpt <= 256 && (cpt & (cpt - 1)) == 0 && (qn == 1 || qn == 2 || qn == 4 || qn == 8);
 }
 
 // CPRP = chunks-per-row padded to a power of two (8 for D <= 64, 16 for D <= 128)
@@ -457,9 +461,9 @@ static void dec_launch_rows(const DecDev& p, int qn, unsigned rows, hipStream_t 
   const dim3 grid((unsigned)p.B, (unsigned)p.nsplit);
 #define MIO_DEC_ROWS(CPR_, QN_) hipLaunchKernelGGL((decode_rows_kernel<T, CPR_, QN_>), grid, dim3(256), 0, st, p)
   if (p.D == 64) {
-    if (qn == 1) MIO_DEC_ROWS(8, 1); else if (qn == 2) MIO_DEC_ROWS(8, 2); else MIO_DEC_ROWS(8, 4);
+    if (qn == 1) MIO_DEC_ROWS(8, 1); else if (qn == 2) MIO_DEC_ROWS(8, 2); else if (qn == 4) MIO_DEC_ROWS(8, 4); else MIO_DEC_ROWS(8, 8);
   } else {
-    if (qn == 1) MIO_DEC_ROWS(16, 1); else if (qn == 2) MIO_DEC_ROWS(16, 2); else MIO_DEC_ROWS(16, 4);
+    if (qn == 1) MIO_DEC_ROWS(16, 1); else if (qn == 2) MIO_DEC_ROWS(16, 2); else if (qn == 4) MIO_DEC_ROWS(16, 4); else MIO_DEC_ROWS(16, 8);
   }
 #undef MIO_DEC_ROWS
   if (p.nsplit > 1) hipLaunchKernelGGL(decode_reduce_kernel<T>, dim3(rows), dim3(128), 0, st, p);
@@ -492,7 +496,10 @@ extern "C" int mio_fa3_decode_paged(const void* q, void* o, const void* k_cache,
   p.os_b = o_stride[0]; p.os_h = o_stride[1]; p.os_s = o_stride[2];
   p.B = B; p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.D = D; p.L = num_layers; p.layer = layer_idx;
   p.bs = block_size; p.max_blocks = max_blocks_per_seq; p.scale = scale;
-  const bool rows_kernel = dec_rows_ok(B, H, Hkv, q_len, D);
+  bool rows_kernel = dec_rows_ok(B, H, Hkv, q_len, D, max_ctx);
+#ifdef MIO_DIAG
+  if (mio_dbg_get(6) == 1) rows_kernel = false;  // A/B: the per-head kernel (tools/dbg/dec_rows_ab.py)
+#endif
   p.nsplit = rows_kernel ? dec_nsplit_rows(B, max_ctx) : dec_nsplit(B, H, q_len, max_ctx);
   int sl = (max_ctx + p.nsplit - 1) / p.nsplit;
   sl = (sl + 31) / 32 * 32;

@@ -597,6 +597,8 @@ def test_layernorm(golden_dir, dtype):
     # whole-token-row kernel geometries: row = 2 / 4 wave-loads (H 16: the bench.py decode leg), two query positions,
     # a row of exactly one wave-load with two query heads per kv head
     (64, 16, 16, 1), (128, 16, 16, 1), (64, 8, 8, 2), (64, 16, 8, 1),
+    # eight query vectors per kv head (GQA 8: H 32 / Hkv 4, and GQA 4 with two query positions)
+    (128, 32, 4, 1), (64, 16, 4, 2),
 ])
 def test_paged_decode_and_cache(dtype, D, H, Hkv, q_len):
     ops = _ops()
