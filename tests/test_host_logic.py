@@ -371,6 +371,11 @@ def test_gemm_kernels_isa_soundness(tmp_path):
             assert re.search(r"\.private_segment_fixed_size:\s+0\b", blk), blk
             assert re.search(r"\.vgpr_spill_count:\s+0\b", blk), blk
         assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 256, blk
+    # (c) no store whose data registers are rewritten by the very next instruction (tools/check_store_war.py: the hazard
+    # behind round 3's wrong lanes -- hipcc leaves no wait state behind a buffer_store with a register soffset)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_store_war.py"), str(isa), "gemm8w_kernel", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
     starts = [i for i, l in enumerate(text) if re.match(r"^_Z1[56]gemm4w16p?_kernel\w+:", l)]
     assert len(starts) >= 10
     for a in starts:
