@@ -1,9 +1,9 @@
 #!/bin/bash
-# Runs ON the GPU box: SQ counters + clock of fwd3 and fwd4 (separate passes; no trace domains besides kernel-trace).
+# Runs ON the GPU box: SQ counters + clock of the attention structures (fa_pmc.py modes; separate passes; no trace domains besides kernel-trace).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/fa_pmc
 rm -rf $OUT; mkdir -p $OUT
-for impl in 3 4; do
+for impl in 5 5p 3; do
   timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/a$impl -o k -- python3 tools/fa_pmc.py $impl 300 > $OUT/a$impl.log 2>&1 || exit 1
   timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC --kernel-trace --output-format csv -d $OUT/b$impl -o k -- python3 tools/fa_pmc.py $impl 300 > $OUT/b$impl.log 2>&1 || exit 1
 done
