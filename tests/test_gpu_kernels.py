@@ -449,12 +449,14 @@ def test_fused_mlp_blocked_intermediate(dtype, act, res, M):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,act,res", [
-    (4096 + 37, 4096 + 8, 1024, "none", False),   # persistent kernel, 1 store / K-tile, ragged M and N, 289 tiles
-    (8192, 2304 + 24, 256, "gelu", False),        # persistent, 4 stores / K-tile, 320 tiles
-    (5000, 3584, 544, "silu", False),             # K % 64 != 0 -> one-tile kernel
-    (4096 + 5, 4096, 512, "gelu_erf", False),     # persistent, 2 stores / K-tile, erf read-out
-    (4352, 4096, 288, "none", True),              # residual epilogue -> one-tile-per-workgroup 256x256 kernel
-    (4352 + 3, 4096, 264, "relu", True),          # K % 32 != 0 -> generic 256x256 kernel
+    (4096 + 37, 4096 + 8, 1024, "none", False),   # gemm8w_kernel, ragged M and N, 289 tiles (2 per workgroup for some)
+    (8192, 2304 + 24, 256, "gelu", False),        # 8 K-tiles, 320 tiles
+    (5000, 3584, 544, "silu", False),             # 17 K-tiles (odd: the LDS stage index runs on across tiles)
+    (4096 + 5, 4096, 512, "gelu_erf", False),     # erf read-out
+    (4352, 4096, 288, "none", True),              # residual read-out, 9 K-tiles
+    (8192 + 100, 4096, 128, "none", True),        # the minimum depth: 4 K-tiles, every K-tile is a boundary case
+    (8192, 4096 + 72, 160, "gelu", False),        # 5 K-tiles
+    (4352 + 3, 4096, 264, "relu", True),          # K % 32 != 0 -> generic 256x256 kernel (32x32x16)
 ])
 def test_gemm_big_tiles(dtype, M, N, K, act, res):
     """The 256x256-tile kernels only run when a launch has >= 256 such tiles (mio gemm_inst.hip launch_act): sizes
