@@ -135,7 +135,11 @@ static int launch_8w(GemmDev p, hipStream_t stream, bool one_tile = false) {
   });
   if (ea != hipSuccess) return mio_fail(std::string("gemm8w: hipFuncSetAttribute: ") + hipGetErrorString(ea));
   const int tiles = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL(kern, dim3((one_tile || tiles < ncu) ? tiles : ncu), dim3(G8_THREADS), G8_SMEM, stream, p);
+  int wgs = ncu;
+#ifdef MIO_DIAG  // mio_dbg_set(7, n): a workgroup budget below the CU count, for co-running with another stream's kernel
+  if (mio_dbg_get(7) >= 8 && mio_dbg_get(7) < ncu) wgs = mio_dbg_get(7) & ~7;  // (tools/overlap_probe.py)
+#endif
+  hipLaunchKernelGGL(kern, dim3((one_tile || tiles < wgs) ? tiles : wgs), dim3(G8_THREADS), G8_SMEM, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mio_fail(std::string("gemm8w launch: ") + hipGetErrorString(e));
   return 0;
