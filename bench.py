@@ -181,6 +181,29 @@ def decode_leg(dt):
             "tokens_per_s": Bd / (ms * 1e-3)}
 
 
+def decode_gqa_leg(dt):
+    """Paged decode with grouped queries (8 query heads per kv head: H 32, Hkv 4, D 128, B 64, ctx 4096 -- 512 MiB of cache):
+    decode_gqa_kernel, the q . K^T / P . V of the 8 (padded to 16) query vectors on the matrix core.  Bound: HBM."""
+    import torch
+    from mio import ops
+
+    Bd, Hd, Hkv, Dd, bs, ctx = 64, 32, 4, 128, 16, 4096
+    nblk = Bd * ctx // bs
+    kc = torch.randn(nblk, 1, bs, Hkv, Dd, device="cuda", dtype=dt)
+    vc = torch.randn(nblk, 1, bs, Hkv, Dd, device="cuda", dtype=dt)
+    bt = torch.randperm(nblk, device="cuda").view(Bd, -1).to(torch.int32)
+    cl = torch.full((Bd,), ctx, device="cuda", dtype=torch.int32)
+    q = torch.randn(Bd, Hd, 1, Dd, device="cuda", dtype=dt)
+    o = torch.empty_like(q)
+    ms = _events_ms(lambda: ops.paged_attention_forward(q, o, kc, vc, bt, cl, bs, ctx, 0), 20, sustain_ms=100.0)
+    nbytes = 2.0 * Bd * ctx * Hkv * Dd * 2
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"workload": f"paged decode q_len 1, B {Bd} H {Hd} Hkv {Hkv} D {Dd} ctx {ctx} block {bs} (random physical blocks)",
+            "kernel": "decode_gqa_kernel + decode_reduce_kernel", "bound": "hbm", "ms": ms, "achieved": gbs,
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "bytes_per_launch": nbytes,
+            "tokens_per_s": Bd / (ms * 1e-3)}
+
+
 def attention_functional_leg(dt):
     """The reference's functional entry point, triton_flash_attention(q, k, v, causal=True) (flash_attention_kernels.py:1150-1358),
     at the C2 attention shape with plain (not pre-scaled) K: fa3_fwd5_kernel's KPRE = false form."""
@@ -433,7 +456,8 @@ def main():
         del model
         torch.cuda.empty_cache()
         extra = res.setdefault("extra", {})
-        for name, leg in (("decode_roofline", lambda: decode_leg(dt)), ("c5", lambda: c5_leg(dt)), ("swiglu", lambda: swiglu_leg(dt)),
+        for name, leg in (("decode_roofline", lambda: decode_leg(dt)), ("decode_gqa_roofline", lambda: decode_gqa_leg(dt)),
+                          ("c5", lambda: c5_leg(dt)), ("swiglu", lambda: swiglu_leg(dt)),
                           ("attention_functional", lambda: attention_functional_leg(dt))):
             try:
                 extra[name] = leg()

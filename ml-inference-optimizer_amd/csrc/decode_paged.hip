@@ -7,6 +7,7 @@
 // Cache layout [num_blocks, num_layers, block_size, Hkv, D]; token t of sequence b lives in physical
 // block block_tables[b, t / block_size] at slot t % block_size (:728-751).
 #include <cstdlib>
+#include <mutex>
 
 #include "mio_common.h"
 
@@ -23,6 +24,37 @@ struct DecDev {
   int B, H, Hkv, q_len, D, L, layer, bs, max_blocks, nsplit, split_len;
   float scale;
 };
+
+#include "decode_gqa_kernel.h"
+
+// decode_gqa_kernel (matrix-core form): one workgroup per (sequence, kv head, split); the split count aims at one
+// (D 128: 136 KiB of LDS) or two (D 64) workgroups per CU, 128-key granularity (4 waves x 32-key chunks)
+static inline int dec_nsplit_gqa(int64_t units, int max_ctx, int bs, int D = 128) {
+  // workgroups aimed for = what is resident at once (D 128: 136 KiB of LDS, one per CU; D 64: two per CU); a second round of
+  // workgroups costs its tail (tools/dbg/dec_gqa_ab.py, B 64 H 32 Hkv 4 D 128: 256 -> 5.68 TB/s, 512 -> 5.37, 2048 -> 4.50)
+  int target = D > 64 ? 256 : 512;
+#ifdef MIO_DIAG
+  if (mio_dbg_get(2) > 0) target = mio_dbg_get(2);
+#endif
+  int want = (int)((target + units - 1) / units);
+  int cap = (max_ctx + 255) / 256;  // >= 256 keys per split
+  if (cap < 1) cap = 1;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  // a split's block-table slice must fit its LDS image
+  while (((int64_t)(max_ctx + want - 1) / want + 127) / bs + 2 > DG_BT_MAX) ++want;
+  return want;
+}
+// Picked when more than 4 query vectors share a cached key ((H / Hkv) * q_len in 5 .. 16): below that the row kernels are
+// HBM-bound already (5.9 TB/s at MHA), above it they are bound by the vector ALU (1.04 TB/s at 8).
+static inline bool dec_gqa_ok(int B, int H, int Hkv, int q_len, int D, int max_ctx, int bs, const int64_t* os, const void* o) {
+  const int qn = (H / Hkv) * q_len;
+  if (qn < 5 || qn > 16) return false;
+  if (D != 64 && D != 128) return false;
+  if (max_ctx < 1) return false;
+  if (os[0] % 8 != 0 || os[1] % 8 != 0 || os[2] % 8 != 0 || !mio_aligned16(o)) return false;  // 16-byte output stores
+  return true;
+}
 
 static inline int dec_nsplit(int B, int H, int q_len, int max_ctx) {
   const int64_t rows = (int64_t)B * H * q_len;
@@ -469,9 +501,28 @@ static void dec_launch_rows(const DecDev& p, int qn, unsigned rows, hipStream_t 
   if (p.nsplit > 1) hipLaunchKernelGGL(decode_reduce_kernel<T>, dim3(rows), dim3(128), 0, st, p);
 }
 
+template <typename T>
+static int dec_launch_gqa(const DecDev& p, unsigned rows, hipStream_t st) {
+  const dim3 grid((unsigned)(p.B * p.Hkv), (unsigned)p.nsplit);
+  static std::once_flag once;
+  static hipError_t ea = hipSuccess;
+  std::call_once(once, [&] {
+    ea = hipFuncSetAttribute((const void*)decode_gqa_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, dg_smem_bytes<128>());
+    if (ea == hipSuccess)
+      ea = hipFuncSetAttribute((const void*)decode_gqa_kernel<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, dg_smem_bytes<64>());
+  });
+  if (ea != hipSuccess) return mio_fail(std::string("decode_gqa: hipFuncSetAttribute: ") + hipGetErrorString(ea));
+  if (p.D == 128) hipLaunchKernelGGL((decode_gqa_kernel<T, 128>), grid, dim3(256), dg_smem_bytes<128>(), st, p);
+  else hipLaunchKernelGGL((decode_gqa_kernel<T, 64>), grid, dim3(256), dg_smem_bytes<64>(), st, p);
+  if (p.nsplit > 1) hipLaunchKernelGGL(decode_reduce_kernel<T>, dim3(rows), dim3(128), 0, st, p);
+  return 0;
+}
+
 extern "C" size_t mio_fa3_decode_workspace_bytes(int32_t B, int32_t H, int32_t q_len, int32_t D, int32_t max_ctx) {
   const int ns_a = dec_nsplit(B, H, q_len, max_ctx), ns_b = dec_nsplit_rows(B, max_ctx);
-  const int ns = ns_a > ns_b ? ns_a : ns_b;  // covers whichever kernel the launch picks (it does not know Hkv here)
+  const int ns_c = dec_nsplit_gqa(B, max_ctx, 1, 64);  // fewest units (Hkv 1), smallest block size, larger target: the largest split count
+  int ns = ns_a > ns_b ? ns_a : ns_b;  // covers whichever kernel the launch picks (it does not know Hkv here)
+  if (ns_c > ns) ns = ns_c;
   return (size_t)B * H * q_len * ns * (size_t)(D + 1) * sizeof(float) + 256;
 }
 
@@ -497,13 +548,18 @@ extern "C" int mio_fa3_decode_paged(const void* q, void* o, const void* k_cache,
   p.B = B; p.H = H; p.Hkv = Hkv; p.q_len = q_len; p.D = D; p.L = num_layers; p.layer = layer_idx;
   p.bs = block_size; p.max_blocks = max_blocks_per_seq; p.scale = scale;
   bool rows_kernel = dec_rows_ok(B, H, Hkv, q_len, D, max_ctx);
+  bool gqa_kernel = dec_gqa_ok(B, H, Hkv, q_len, D, max_ctx, block_size, o_stride, o);
 #ifdef MIO_DIAG
-  if (mio_dbg_get(6) == 1) rows_kernel = false;  // A/B: the per-head kernel (tools/dbg/dec_rows_ab.py)
+  if (mio_dbg_get(6) == 1) rows_kernel = gqa_kernel = false;  // A/B: the per-head kernel (tools/dbg/dec_rows_ab.py)
+  if (mio_dbg_get(6) == 2) gqa_kernel = false;                // A/B: rows kernel where it applies
 #endif
-  p.nsplit = rows_kernel ? dec_nsplit_rows(B, max_ctx) : dec_nsplit(B, H, q_len, max_ctx);
+  if (gqa_kernel) rows_kernel = false;
+  p.nsplit = gqa_kernel ? dec_nsplit_gqa((int64_t)B * Hkv, max_ctx, block_size, D)
+                        : rows_kernel ? dec_nsplit_rows(B, max_ctx) : dec_nsplit(B, H, q_len, max_ctx);
   int sl = (max_ctx + p.nsplit - 1) / p.nsplit;
-  sl = (sl + 31) / 32 * 32;
-  if (sl < 32) sl = 32;
+  const int gran = gqa_kernel ? 128 : 32;
+  sl = (sl + gran - 1) / gran * gran;
+  if (sl < gran) sl = gran;
   p.split_len = sl;
   MIO_CHECK(p.nsplit == 1 || workspace != nullptr, "mio_fa3_decode_paged: workspace required");
   const int64_t rows = (int64_t)B * H * q_len;
@@ -511,7 +567,10 @@ extern "C" int mio_fa3_decode_paged(const void* q, void* o, const void* k_cache,
   p.ws_lse = p.ws_o ? p.ws_o + rows * p.nsplit * D : nullptr;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)rows, (unsigned)p.nsplit), block(256);
-  if (rows_kernel) {
+  if (gqa_kernel) {
+    const int rc = (dtype == MIO_BF16) ? dec_launch_gqa<__bf16>(p, (unsigned)rows, st) : dec_launch_gqa<_Float16>(p, (unsigned)rows, st);
+    if (rc != 0) return rc;
+  } else if (rows_kernel) {
     if (dtype == MIO_BF16) dec_launch_rows<__bf16>(p, (H / Hkv) * q_len, (unsigned)rows, st);
     else dec_launch_rows<_Float16>(p, (H / Hkv) * q_len, (unsigned)rows, st);
   } else if (dtype == MIO_BF16) dec_launch<__bf16>(p, grid, st);

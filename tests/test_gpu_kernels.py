@@ -601,6 +601,9 @@ def test_layernorm(golden_dir, dtype):
     (64, 16, 16, 1), (128, 16, 16, 1), (64, 8, 8, 2), (64, 16, 8, 1),
     # eight query vectors per kv head (GQA 8: H 32 / Hkv 4, and GQA 4 with two query positions)
     (128, 32, 4, 1), (64, 16, 4, 2),
+    # matrix-core GQA kernel (5 .. 16 query vectors per kv head): 16 (all MFMA columns live), 6 and 12 (not powers of two,
+    # three query positions), 16 as 8 heads x 2 positions at D 64, and B 3 (fewer workgroups than CUs)
+    (128, 32, 2, 1), (64, 12, 2, 1), (64, 8, 2, 3), (64, 16, 2, 2), (128, 6, 1, 1),
 ])
 def test_paged_decode_and_cache(dtype, D, H, Hkv, q_len):
     ops = _ops()
@@ -651,6 +654,34 @@ def test_paged_decode_pipelined_batches():
         ops.paged_attention_forward(q.to(DEV), out, kc.to(DEV), vc.to(DEV), bt.to(DEV), ctx.to(DEV), bs, 1280, 0)
         _cmp(out, oracle.paged_attention_forward(q, kc, vc, bt, ctx, bs, 0), dtype, f"paged U={unroll} D={D}")
         assert out[5].abs().max() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("D,H,Hkv,q_len,bs", [(128, 32, 4, 1, 16), (64, 32, 4, 1, 16), (128, 16, 1, 1, 8), (64, 10, 2, 1, 12),
+                                              (128, 8, 1, 2, 1)])
+def test_paged_decode_gqa_long_contexts(dtype, D, H, Hkv, q_len, bs):
+    """decode_gqa_kernel over contexts of several splits and many 32-key chunks per wave: ends inside a chunk, at a chunk / 128-key /
+    split boundary, one key, none; block sizes 16, 8, 12 (not a power of two) and 1; random physical blocks; layer 1 of 2."""
+    ops = _ops()
+    torch.manual_seed(D + H + bs)
+    ctxs = [5000, 4096, 4097, 2047, 1311, 129, 128, 33, 32, 31, 1, 0]
+    B, L = len(ctxs), 2
+    maxb = (5000 + bs - 1) // bs + 1
+    nblk = B * maxb
+    ctx = torch.tensor(ctxs, dtype=torch.int32)
+    kc = torch.randn(nblk, L, bs, Hkv, D).to(dtype)
+    vc = torch.randn(nblk, L, bs, Hkv, D).to(dtype)
+    bt = torch.randperm(nblk).view(B, maxb).to(torch.int32)
+    q = (torch.randn(B, H, q_len, D) * 1.5).to(dtype)
+    out = torch.full((B, H, q_len, D), float("nan"), dtype=dtype, device=DEV)
+    ops.paged_attention_forward(q.to(DEV), out, kc.to(DEV), vc.to(DEV), bt.to(DEV), ctx.to(DEV), bs, 5000, 1)
+    _cmp(out, oracle.paged_attention_forward(q, kc, vc, bt, ctx, bs, 1), dtype, f"gqa decode D={D} H={H}/{Hkv} q_len={q_len} bs={bs}")
+    assert out[-1].abs().max() == 0
+    # a strided (non-contiguous in H) output tensor still lands in the right rows
+    big = torch.zeros(B, H, q_len, 2 * D, dtype=dtype, device=DEV)
+    view = big[..., :D]
+    ops.paged_attention_forward(q.to(DEV), view, kc.to(DEV), vc.to(DEV), bt.to(DEV), ctx.to(DEV), bs, 5000, 1)
+    assert torch.equal(view, out) and big[..., D:].abs().max() == 0
 
 
 def test_errors_raise_before_launch():
