@@ -45,11 +45,14 @@ static inline int dec_nsplit_gqa(int64_t units, int max_ctx, int bs, int D = 128
   while (((int64_t)(max_ctx + want - 1) / want + 127) / bs + 2 > DG_BT_MAX) ++want;
   return want;
 }
-// Picked when more than 4 query vectors share a cached key ((H / Hkv) * q_len in 5 .. 16): below that the row kernels are
-// HBM-bound already (5.9 TB/s at MHA), above it they are bound by the vector ALU (1.04 TB/s at 8).
+// Picked when 2 .. 16 query vectors share a cached key ((H / Hkv) * q_len): the vector-ALU kernels are HBM-bound with one
+// (5.7-5.9 TB/s at MHA) and fall off from there -- tools/dbg/dec_gqa_small_qn.py, shipped-before vs this kernel: 2 vectors
+// 5.52 -> 6.16 TB/s (D 128, B 64), 2.31 -> 3.25 (D 64, B 8), 5.46 -> 5.25 (D 64, two query positions: the one loss); 3 vectors
+// 2.36 -> 5.75; 4 vectors 3.32 -> 5.48 and 1.67 -> 4.89 at B 1 x ctx 131072; 8 vectors 1.04 -> 5.4-5.7.  With one vector it
+// is 8 % slower at D 64 (5.20 vs 5.68) and 2 % faster at D 128: left to the row kernels.
 static inline bool dec_gqa_ok(int B, int H, int Hkv, int q_len, int D, int max_ctx, int bs, const int64_t* os, const void* o) {
   const int qn = (H / Hkv) * q_len;
-  if (qn < 5 || qn > 16) return false;
+  if (qn < 2 || qn > 16) return false;
   if (D != 64 && D != 128) return false;
   if (max_ctx < 1) return false;
   if (os[0] % 8 != 0 || os[1] % 8 != 0 || os[2] % 8 != 0 || !mio_aligned16(o)) return false;  // 16-byte output stores
@@ -100,7 +103,7 @@ static inline bool dec_rows_ok(int B, int H, int Hkv, int q_len, int D, int max_
   if (B < 16 && (B < 8 || kv_bytes <= 200.0 * 1048576.0)) return false;
   if (D != 64 && D != 128) return false;
   const int cpt = Hkv * (D / 8), qn = (H / Hkv) * q_len;
-  return cpt >= 16 && cpt <= 256 && (cpt & (cpt - 1)) == 0 && (qn == 1 || qn == 2 || qn == 4 || qn == 8);
+  return cpt >= 16 && cpt <= 256 && (cpt & (cpt - 1)) == 0 && qn == 1;  // 2 .. 16 query vectors per key: decode_gqa_kernel
 }
 
 // CPRP = chunks-per-row padded to a power of two (8 for D <= 64, 16 for D <= 128)
@@ -492,11 +495,9 @@ template <typename T>
 static void dec_launch_rows(const DecDev& p, int qn, unsigned rows, hipStream_t st) {
   const dim3 grid((unsigned)p.B, (unsigned)p.nsplit);
 #define MIO_DEC_ROWS(CPR_, QN_) hipLaunchKernelGGL((decode_rows_kernel<T, CPR_, QN_>), grid, dim3(256), 0, st, p)
-  if (p.D == 64) {
-    if (qn == 1) MIO_DEC_ROWS(8, 1); else if (qn == 2) MIO_DEC_ROWS(8, 2); else if (qn == 4) MIO_DEC_ROWS(8, 4); else MIO_DEC_ROWS(8, 8);
-  } else {
-    if (qn == 1) MIO_DEC_ROWS(16, 1); else if (qn == 2) MIO_DEC_ROWS(16, 2); else if (qn == 4) MIO_DEC_ROWS(16, 4); else MIO_DEC_ROWS(16, 8);
-  }
+  (void)qn;  // always 1 (dec_rows_ok); the kernel template keeps QN for the diagnostic sweeps
+  if (p.D == 64) MIO_DEC_ROWS(8, 1);
+  else MIO_DEC_ROWS(16, 1);
 #undef MIO_DEC_ROWS
   if (p.nsplit > 1) hipLaunchKernelGGL(decode_reduce_kernel<T>, dim3(rows), dim3(128), 0, st, p);
 }
@@ -552,6 +553,9 @@ extern "C" int mio_fa3_decode_paged(const void* q, void* o, const void* k_cache,
 #ifdef MIO_DIAG
   if (mio_dbg_get(6) == 1) rows_kernel = gqa_kernel = false;  // A/B: the per-head kernel (tools/dbg/dec_rows_ab.py)
   if (mio_dbg_get(6) == 2) gqa_kernel = false;                // A/B: rows kernel where it applies
+  if (mio_dbg_get(6) == 3)                                    // A/B: the matrix-core kernel for 1 .. 4 query vectors too
+    gqa_kernel = (H / Hkv) * q_len <= 16 && (D == 64 || D == 128) && o_stride[0] % 8 == 0 && o_stride[1] % 8 == 0 &&
+                 o_stride[2] % 8 == 0 && mio_aligned16(o);
 #endif
   if (gqa_kernel) rows_kernel = false;
   p.nsplit = gqa_kernel ? dec_nsplit_gqa((int64_t)B * Hkv, max_ctx, block_size, D)

@@ -601,7 +601,8 @@ def test_layernorm(golden_dir, dtype):
     (64, 16, 16, 1), (128, 16, 16, 1), (64, 8, 8, 2), (64, 16, 8, 1),
     # eight query vectors per kv head (GQA 8: H 32 / Hkv 4, and GQA 4 with two query positions)
     (128, 32, 4, 1), (64, 16, 4, 2),
-    # matrix-core GQA kernel (5 .. 16 query vectors per kv head): 16 (all MFMA columns live), 6 and 12 (not powers of two,
+    # matrix-core GQA kernel (2 .. 16 query vectors per kv head; the two rows above and (64, 8, 8, 2), (64, 16, 8, 1), (128, 8, 2, 1)
+    # take it too): 16 (all MFMA columns live), 6 and 12 (not powers of two,
     # three query positions), 16 as 8 heads x 2 positions at D 64, and B 3 (fewer workgroups than CUs)
     (128, 32, 2, 1), (64, 12, 2, 1), (64, 8, 2, 3), (64, 16, 2, 2), (128, 6, 1, 1),
 ])
