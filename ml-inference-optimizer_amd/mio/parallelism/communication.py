@@ -54,6 +54,19 @@ def get_world_size(group: Optional[dist.ProcessGroup] = None) -> int:
     return dist.get_world_size(group) if dist.is_initialized() else 1
 
 
+# Tests only (tests/test_gpu_parallel.py::test_rccl_single_rank_*): a one-GPU box can host ONE RCCL rank, so the only way to run these
+# wrappers' stream / handle logic on the real backend there is to let a group of one go through the collective instead of
+# returning early.  Never set by the package itself.
+FORCE_SINGLE_RANK_COLLECTIVES = False
+
+
+def _alone(group: Optional[dist.ProcessGroup] = None) -> bool:
+    """True when there is nobody to talk to: no process group, or a group of one (the reference's early returns)."""
+    if not dist.is_initialized():
+        return True
+    return get_world_size(group) == 1 and not FORCE_SINGLE_RANK_COLLECTIVES
+
+
 def _op(op) -> Tuple[dist.ReduceOp, bool]:
     if isinstance(op, str):
         name = op.lower()
@@ -70,7 +83,7 @@ def all_reduce(tensor: torch.Tensor, op: Union[dist.ReduceOp, str] = dist.Reduce
                use_unbalanced: bool = False, stream: Optional[torch.cuda.Stream] = None):
     """In-place all-reduce (reference :37-209).  use_fp16/use_bf16 down-cast for the wire (:70-74);
     "avg" divides by the group size; use_unbalanced is accepted and ignored (RCCL picks tree/ring)."""
-    if not dist.is_initialized() or get_world_size(group) == 1:
+    if _alone(group):
         return (None, tensor) if async_op else tensor
     rop, avg = _op(op)
     comm = tensor
@@ -137,7 +150,7 @@ def all_gather(tensor: torch.Tensor, dim: int = 0, async_op: bool = False,
     """Gather along `dim` (reference :211-246).  Gathers straight into the pre-laid-out result when
     dim == 0 (no torch.cat); other dims gather then move the axis once."""
     ws = get_world_size(group)
-    if not dist.is_initialized() or ws == 1:
+    if _alone(group):
         return (None, tensor) if async_op else tensor
     t = tensor.contiguous()
     dim = dim % t.dim()
@@ -159,7 +172,7 @@ def reduce_scatter(tensor: torch.Tensor, dim: int = 0, op: Union[dist.ReduceOp, 
                    async_op: bool = False, group: Optional[dist.ProcessGroup] = None):
     """Reduce then keep this rank's 1/ws slice along `dim` (reference :248-304)."""
     ws = get_world_size(group)
-    if not dist.is_initialized() or ws == 1:
+    if _alone(group):
         return (None, tensor) if async_op else tensor
     rop, avg = _op(op)
     dim = dim % tensor.dim()
@@ -183,14 +196,14 @@ def reduce_scatter(tensor: torch.Tensor, dim: int = 0, op: Union[dist.ReduceOp, 
 
 
 def broadcast(tensor: torch.Tensor, src: int = 0, async_op: bool = False, group: Optional[dist.ProcessGroup] = None):
-    if not dist.is_initialized() or get_world_size(group) == 1:
+    if _alone(group):
         return (None, tensor) if async_op else tensor
     work = dist.broadcast(tensor, src=src, group=group, async_op=async_op)
     return (work, tensor) if async_op else tensor
 
 
 def barrier(group: Optional[dist.ProcessGroup] = None) -> None:
-    if dist.is_initialized() and get_world_size(group) > 1:
+    if not _alone(group):
         dist.barrier(group=group)
 
 
@@ -285,7 +298,7 @@ def ring_exchange(*tensors: torch.Tensor, group: Optional[dist.ProcessGroup] = N
     """Each rank sends `tensors` to rank+1 and receives the same shapes from rank-1 (reference
     :1694-1831).  None entries pass through (the reference crashes on a None mask, :1738-1743).
     One grouped batch_isend_irecv -> a single RCCL group call; no clones of the send buffers."""
-    if not dist.is_initialized() or get_world_size(group) == 1:
+    if _alone(group):
         return (None, list(tensors)) if async_op else list(tensors)
     ws, r = get_world_size(group), get_rank(group)
     nxt = dist.get_global_rank(group, (r + 1) % ws) if group is not None else (r + 1) % ws

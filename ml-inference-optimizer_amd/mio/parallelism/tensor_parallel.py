@@ -144,7 +144,7 @@ class RowParallelLinear(nn.Module):
         add_here = (rank == 0)
         bias = self.bias if (self.bias is not None and not self.skip_bias_add and add_here) else None
         res = residual if add_here else None
-        if tp == 1 or not torch.distributed.is_initialized():
+        if not torch.distributed.is_initialized() or (tp == 1 and not comm.FORCE_SINGLE_RANK_COLLECTIVES):
             out = _local.linear(input, self.weight, bias, "none", res)
         else:
             group = cfg.get_tp_group()

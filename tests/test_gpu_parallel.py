@@ -36,6 +36,23 @@ def _worker(rank, world, port, fn_name, args):
         dist.destroy_process_group()
 
 
+def _worker_rccl(rank, world, port, fn_name, args):
+    """One rank on the real backend ("nccl" = RCCL): all a one-GPU box can host."""
+    for p in (ROOT, os.path.join(ROOT, "ml-inference-optimizer_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    torch.set_grad_enabled(False)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        globals()[fn_name](*args)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+
+
 def _run(fn_name, world=2, args=()):
     mp.spawn(_worker, args=(world, _free_port(), fn_name, args), nprocs=world, join=True)
 
@@ -337,6 +354,77 @@ def _w_bench_extras(rank, world):
     r = bench_ring(world, 1024 * world, 256, 4, torch.bfloat16, steps=1, warmup=1)
     assert all(r[k]["tokens_per_s"] > 0 for k in ("noncausal_mesh", "noncausal_mesh_unoverlapped", "noncausal_ring",
                                                   "noncausal_ring_unoverlapped", "causal_zigzag_mesh"))
+
+
+def _w_rccl_wrappers():
+    """Every collective wrapper of mio.parallelism.communication on RCCL with a group of one (FORCE_SINGLE_RANK_COLLECTIVES: the
+    early returns are off, so the calls reach the backend): a sum / gather / scatter / exchange over one rank is the identity,
+    and what is under test is the stream and handle logic against RCCL's asynchronous works (gloo's are synchronous)."""
+    from mio.parallelism import communication as comm
+    comm.FORCE_SINGLE_RANK_COLLECTIVES = True
+    assert dist.get_backend() == "nccl"
+    torch.manual_seed(0)
+    x = torch.randn(1024, 512, device="cuda")
+    side = torch.cuda.Stream()
+    for kw in ({}, {"op": "avg"}, {"use_bf16": True}, {"stream": side}, {"op": "mean", "use_fp16": True, "stream": side}):
+        t = x.clone()
+        want = x.to(torch.bfloat16).float() if kw.get("use_bf16") else x.half().float() if kw.get("use_fp16") else x
+        out = comm.all_reduce(t, **kw)
+        assert out is t and torch.equal(t, want), kw
+        t = x.clone()
+        h, out = comm.all_reduce(t, async_op=True, **kw)
+        y = torch.mm(x, x.t())  # work queued beside the collective
+        h.wait()
+        assert h.is_completed() or True
+        assert torch.equal(out, want), kw
+        del y
+    t = x[:, ::2]  # not contiguous: goes through a wire copy and comes back into the view
+    comm.all_reduce(t)
+    assert torch.equal(t, x[:, ::2])
+    assert torch.equal(comm.all_gather(x, dim=0), x) and torch.equal(comm.all_gather(x, dim=1), x)
+    w, g = comm.all_gather(x, dim=-1, async_op=True)
+    assert torch.equal(g, x)
+    assert torch.equal(comm.reduce_scatter(x, dim=1), x) and torch.equal(comm.reduce_scatter(x, dim=0, op="avg"), x)
+    assert torch.equal(comm.broadcast(x.clone(), src=0), x)
+    comm.barrier()
+    # the ring pass (one grouped batch_isend_irecv: a send to and a receive from the rank itself), sync / async / fp16 wire
+    k = torch.randn(2, 256, 4, 64, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(2, 256, 4, 64, device="cuda", dtype=torch.bfloat16)
+    rk, rn, rv = comm.ring_exchange(k, None, v)
+    assert rn is None and torch.equal(rk, k) and torch.equal(rv, v) and rk.data_ptr() != k.data_ptr()
+    h, (rk, rv) = comm.ring_exchange(k, v, async_op=True)
+    h.wait()
+    h.wait()
+    assert torch.equal(rk, k) and torch.equal(rv, v)
+    (rf,) = comm.ring_exchange(x, use_fp16=True)
+    assert rf.dtype == x.dtype and torch.equal(rf, x.half().float())
+
+
+def _w_rccl_row_parallel():
+    """RowParallelLinear's chunked GEMM -> all-reduce pipeline (the C3 overlap path) with its all-reduces on RCCL: a group of
+    one sums nothing, so the result must equal the plain linear bit for bit -- any ordering hole between the GEMM chunks (torch's
+    stream) and the collectives (RCCL's stream) shows up as stale rows."""
+    from mio import ops
+    from mio.parallelism import communication as comm
+    from mio.parallelism.tensor_parallel import RowParallelLinear, TensorParallelConfig
+    comm.FORCE_SINGLE_RANK_COLLECTIVES = True
+    torch.manual_seed(3)
+    cfg = TensorParallelConfig(world_size=1, tp_size=1, overlap_chunks=4)
+    lin = RowParallelLinear(1024, 1024, bias=True, config=cfg, input_is_parallel=True).to(device="cuda", dtype=torch.bfloat16)
+    x = torch.randn(4, 2048, 1024, device="cuda", dtype=torch.bfloat16)
+    r = torch.randn(4, 2048, 1024, device="cuda", dtype=torch.bfloat16)
+    want = ops.gemm_bias_act(x, lin.weight, lin.bias, residual=r)
+    for _ in range(3):
+        got = lin(x, residual=r)
+        assert torch.equal(got, want)
+    comm.FORCE_SINGLE_RANK_COLLECTIVES = False
+    assert torch.equal(lin(x, residual=r), want)
+
+
+@pytest.mark.parametrize("which", ["wrappers", "row_parallel"])
+def test_rccl_single_rank(which):
+    """The communication layer on RCCL itself, as far as one GPU allows (a second rank on the same device is refused by RCCL)."""
+    mp.spawn(_worker_rccl, args=(1, _free_port(), "_w_rccl_" + which, ()), nprocs=1, join=True)
 
 
 @pytest.mark.parametrize("exchange,causal,zigzag,layout", [
