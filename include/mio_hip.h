@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MIO_VERSION 103 /* 0.1.0 */
+#define MIO_VERSION 104 /* 0.1.0 */
 
 typedef enum { MIO_BF16 = 0, MIO_FP16 = 1 } mio_dtype_t;
 
@@ -181,6 +181,33 @@ int mio_fused_mlp_glu_fwd_bw(const void* x, const void* wgu_b, const void* b_up,
  * elements, ldx ignored) -- what mio_layernorm_fwd_bx writes, so that LayerNorm -> GEMM hands over contiguous K-tiles. */
 int mio_layernorm_fwd_bx(const void* x, const void* residual, const void* weight, const void* bias, void* yb,
                          void* sum_out, int64_t rows, int32_t cols, float eps, float alpha, int32_t dtype, void* stream);
+
+/* LayerNorm folded into the GEMMs on either side of it.  Replaces the reference's LayerNorm -> QKV prologue
+ * fusion (kernels/triton/fused_layernorm_qkv.py:37-420, triton_fused_layernorm_qkv) and its residual + LayerNorm pass
+ * (kernels/triton/layernorm_kernels.py:35-188) between two GEMMs of a transformer block:
+ *   producer = the GEMM that writes the residual stream (out-proj / fc2 with the residual epilogue): stats_out != NULL makes it
+ *     also write, per output row and 256-column tile, (sum, sum of squares) of the ROUNDED row: [N / 256][ceil(M/256)*256][2]
+ *     fp32 (mio_ln_stats_bytes(M, N)); deterministic (fixed summation order, no atomics);
+ *   consumer = the projection behind the LayerNorm: ln_stats (a producer's stats_out of width K) + ln_cvec != NULL: x is the raw
+ *     stream, wb = mio_weight_block of the gamma-scaled weight, bias the beta-folded bias, ln_cvec[n] = sum_k w'[n][k]
+ *     (all three from mio_ln_fold_weight); the read-out computes rstd * (x w'^T - mean * cvec) + bias, then act / column scale.
+ * flags: the operands in the blocked activation layout ((256-row, 32-column) blocks of 16 KiB, rows padded to 256; ld* ignored
+ * for a blocked operand): x (as mio_gemm_bias_act_bw's x_blocked), y (what the next GEMM takes as blocked x), residual.
+ * Shapes: mio_gemm_ln_ok(M, N, K, act, fold_in, stats_out) != 0 (blocked-weight shapes; fold_in: K % 256 == 0, K <= 2048, act
+ * none / gelu_tanh; stats_out: N % 256 == 0, N <= 2048, act none).  Without ln_stats and stats_out it is mio_gemm_bias_act_bw
+ * (+ column scale) with blocked y / residual. */
+#define MIO_GEMM_X_BLOCKED 1
+#define MIO_GEMM_Y_BLOCKED 2
+#define MIO_GEMM_RES_BLOCKED 4
+size_t mio_ln_stats_bytes(int64_t M, int32_t width);
+int32_t mio_gemm_ln_ok(int64_t M, int32_t N, int32_t K, int32_t act, int32_t fold_in, int32_t stats_out);
+/* w [N, K] (row stride ldw), gamma / beta [K] (beta nullable), bias [N] (nullable), all in dtype; w_scaled [N, K] contiguous
+ * = w * gamma (rounded once), cvec [N] fp32 = row sums of w_scaled, bias_out [N] = bias + w beta.  One-time weight preparation. */
+int mio_ln_fold_weight(const void* w, int64_t ldw, const void* gamma, const void* beta, const void* bias, void* w_scaled,
+                       float* cvec, void* bias_out, int32_t N, int32_t K, int32_t dtype, void* stream);
+int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, const void* residual, void* y, int64_t M, int32_t N, int32_t K,
+                   int64_t ldx, int64_t ldy, int64_t ldr, int32_t act, int32_t dtype, int32_t flags, const float* ln_stats,
+                   const float* ln_cvec, float ln_eps, float* stats_out, int32_t cs_lo, int32_t cs_hi, float cs_val, void* stream);
 
 /* LayerNorm / residual+LayerNorm rows (the step either side of attention):
  * sum = x + alpha*residual (if residual), y = (sum-mean)/sqrt(var+eps)*weight + bias.

@@ -58,11 +58,22 @@
 constexpr int G8_THREADS = 512;
 constexpr int G8_BIAS_OFF = G6_SMEM;  // 8 waves x 256 B: each wave's slice of the bias row(s)
 constexpr int G8_SMEM = G6_SMEM + 8 * 256;
+// LayerNorm fold (FOLD != 0): per-wave fp32 column-vector slot, the row-statistics region (consumer: [group][slot <= 8][128 rows]
+// (sum, sum of squares); producer: [group][column quarter][128 rows]) and the producer's arrival counters
+constexpr int G8_CVEC_OFF = G8_SMEM;
+constexpr int G8_STAT_OFF = G8_CVEC_OFF + 8 * 256;
+constexpr int G8_CNT_OFF = G8_STAT_OFF + 2 * 8192;
+constexpr int G8_SMEM_FOLD = G8_CNT_OFF + 64;
+constexpr int G8_LN_SLOTS_MAX = 8;
 
 // VAR (timing-only ablations, diagnostic library): 4 = no prefetch issue in the loop, 16 = no counted wait,
 // 64 = every piece re-reads K-tile 0, 128 = in-kernel stamps (tools/gemm8_stamps.py), 256 = scalar activation math,
 // 2048 = all eight activation fragments read in the read segment
-template <typename T, int ACT, bool RES, int VAR = 0>
+// FOLD (GemmDev, "LayerNorm folded into the GEMMs on either side of it"): 1 = consumer (the read-out normalises: (acc - mean *
+// cvec) * rstd + bias, row statistics from p.ln_stats), 2 = producer (the read-out also writes the rounded output rows' (sum, sum
+// of squares) per tile column: the four column-quarter waves of a group leave their partials in LDS, the last one to arrive adds
+// them in a fixed order -- deterministic -- and stores 128 rows x 8 bytes)
+template <typename T, int ACT, bool RES, int VAR = 0, int FOLD = 0>
 __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
   using X8 = typename DT<T>::x8;
   using X4 = typename DT<T>::x4;
@@ -73,6 +84,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
   constexpr int ONT = WN / 16;         // output column tiles per wave
   constexpr int NCH = 4 * ONT;         // 16-byte output chunks per lane and tile: chunk j = (row pair j / ONT, column tile j % ONT)
   static_assert(!(GLU && RES), "no residual on the gated stage");
+  static_assert(FOLD == 0 || !GLU, "the LayerNorm fold is not built for the gated stage");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -194,6 +206,9 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  if constexpr (FOLD == 2) {  // arrival counters (LDS is not cleared between workgroups); the prologue's barrier publishes them
+    if (tid < 2) ((MIO_LDS unsigned*)(smem + G8_CNT_OFF))[tid] = 0u;
+  }
   int tile = blockIdx.x;  // the launcher keeps gridDim.x <= ntiles
   setup(tile);
   issue_tile(0, 0);
@@ -240,6 +255,23 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
       const uint32_t lds = (uint32_t)(size_t)((MIO_LDS char*)(smem + G8_BIAS_OFF + wave * 256));
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(lds), "v"(src) : "memory", "m0");
     }
+    if constexpr (FOLD == 1) {
+      // column vector (this wave's 64 columns, fp32) and the row statistics of the group's 128 rows (wave wn requests rows
+      // 32 wn .. 32 wn + 31 of every slot: 256 contiguous bytes per slot).  Older than the tail's loads like the bias request;
+      // the statistics are read by the group's other waves too: the tail's barriers stand between these waits and the read-out.
+      const int l = lane_now();
+      const float* csrc = p.ln_cvec + (on0 + l < p.N ? on0 + l : p.N - 1);
+      const uint32_t clds = (uint32_t)(size_t)((MIO_LDS char*)(smem + G8_CVEC_OFF + wave * 256));
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(clds), "v"(csrc) : "memory", "m0");
+      const int64_t mpad = (int64_t)p.tiles_m * 256;
+      const float* ssrc = p.ln_stats + (om0 + 32 * wn) * 2 + l;
+      const uint32_t slds = (uint32_t)(size_t)((MIO_LDS char*)(smem + G8_STAT_OFF + grp * 8192 + wn * 256));
+      for (int s = 0; s < p.ln_slots; ++s) {
+        const float* src = ssrc + (int64_t)s * mpad * 2;
+        const uint32_t dst = slds + s * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
+      }
+    }
     const int next = tile + (int)gridDim.x;
     const bool has_next = next < ntiles;
     if (has_next) setup(next);  // (no next tile: K-tiles 0..2 of this one are fetched again into idle stages, never read)
@@ -283,33 +315,62 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
       int rvo = 0, rstep = 0;
       if constexpr (RES) {
         // (a wave tile that lies completely past M or N stores nothing: its loads read the matrix' first rows / columns)
-        const int64_t rb = ((omrem > 0 ? om0 : 0) * p.ldr + (onrem > 0 ? on0 : 0)) * 2;
+        const int64_t rm = omrem > 0 ? om0 : 0;
+        const int rn = onrem > 0 ? on0 : 0;
+        const int64_t rb = p.res_blk ? ((((rm >> 8) * (int64_t)(p.N >> 5) + (rn >> 5)) << 14) + (rm & 255) * 64) : (rm * p.ldr + rn) * 2;
         const uint32_t rlo = __builtin_amdgcn_readfirstlane((uint32_t)rb), rhi = __builtin_amdgcn_readfirstlane((uint32_t)(rb >> 32));
         rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.res + (((uint64_t)rhi << 32) | rlo)), 0, 0x7fffffff, 0x00020000);
-        rvo = (c16 * (int)p.ldr + 4 * g) * 2;  // accumulator layout: row c16 (+16 for the pair's second tile), columns 4 g ..
-        rstep = 64 * (int)p.ldr;
+        rvo = p.res_blk ? c16 * 64 + 8 * g : (c16 * (int)p.ldr + 4 * g) * 2;  // accumulator layout: row c16 (+16 for the pair's second tile), columns 4 g ..
+        rstep = p.res_blk ? 2048 : 64 * (int)p.ldr;
       }
+      const int rchi = (RES && p.res_blk) ? 16384 : 64;   // bytes from column tile nt to nt + 2 of the residual
+      const int rrow = (RES && p.res_blk) ? 64 : (int)p.ldr * 2;  // bytes per residual row
       u32x4_t keep[NCH];
 #pragma unroll
       for (int mtp = 0; mtp < 4; ++mtp) {
         u32x2_t resA[ONT], resB[ONT];
         if constexpr (RES) {
           // rows past M: clamped to the tile's first row (their results are never stored)
-          const int oa = (full || mtp * 32 + c16 < omrem) ? rvo + mtp * rstep : rvo - c16 * (int)p.ldr * 2;
-          const int ob = (full || mtp * 32 + 16 + c16 < omrem) ? rvo + mtp * rstep + (rstep >> 1) : rvo - c16 * (int)p.ldr * 2;
+          const int oa = (full || mtp * 32 + c16 < omrem) ? rvo + mtp * rstep : rvo - c16 * rrow;
+          const int ob = (full || mtp * 32 + 16 + c16 < omrem) ? rvo + mtp * rstep + (rstep >> 1) : rvo - c16 * rrow;
 #pragma unroll
           for (int nt = 0; nt < ONT; ++nt) {
-            const int cofs = (full || nt * 16 + 4 * g < onrem) ? nt * 32 : -8 * g;
+            const int cofs = (full || nt * 16 + 4 * g < onrem) ? (nt & 1) * 32 + (nt >> 1) * rchi : -8 * g;
             resA[nt] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rrs, oa + cofs, 0, 0));
             resB[nt] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rrs, ob + cofs, 0, 0));
           }
         }
         const bool mok = full || (mtp * 32 + rS < omrem);
+        // FOLD 1: rstd and mean * rstd of this lane's two rows (32 mtp + c16 and + 16) from the slots' (sum, sum of squares)
+        f32x2_t rsA = {1.f, 1.f}, rsB = {1.f, 1.f}, mrA = {0.f, 0.f}, mrB = {0.f, 0.f};
+        if constexpr (FOLD == 1) {
+          const MIO_LDS char* sl = (const MIO_LDS char*)(smem + G8_STAT_OFF + grp * 8192) + (mtp * 32 + c16) * 8;
+          float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
+          for (int s = 0; s < p.ln_slots; ++s) {
+            const f32x2_t va = *(const MIO_LDS f32x2_t*)(sl + s * 1024), vb = *(const MIO_LDS f32x2_t*)(sl + s * 1024 + 128);
+            sa += va[0]; qa += va[1]; sb += vb[0]; qb += vb[1];
+          }
+          const float ik = 1.f / (float)p.K;
+          const float ma = sa * ik, mb = sb * ik;
+          const float ra = __builtin_amdgcn_rsqf(fmaxf(qa * ik - ma * ma, 0.f) + p.ln_eps);
+          const float rb = __builtin_amdgcn_rsqf(fmaxf(qb * ik - mb * mb, 0.f) + p.ln_eps);
+          rsA = (f32x2_t){ra, ra}; rsB = (f32x2_t){rb, rb};
+          mrA = (f32x2_t){ma * ra, ma * ra}; mrB = (f32x2_t){mb * rb, mb * rb};
+        }
+        float stA = 0.f, sqA = 0.f, stB = 0.f, sqB = 0.f;  // FOLD 2: this lane's share of the two rows' (sum, sum of squares)
 #pragma unroll
         for (int nt = 0; nt < ONT; ++nt) {
-          const f32x4_t a = acc[2 * mtp][nt], b = acc[2 * mtp + 1][nt];
+          f32x4_t a = acc[2 * mtp][nt], b = acc[2 * mtp + 1][nt];
           const X4 bv = __builtin_bit_cast(X4, bq[nt]);
-          const f32x2_t b01 = {(float)bv[0], (float)bv[1]}, b23 = {(float)bv[2], (float)bv[3]};
+          f32x2_t b01 = {(float)bv[0], (float)bv[1]}, b23 = {(float)bv[2], (float)bv[3]};
+          if constexpr (FOLD == 1) {  // (acc - mean * cvec) * rstd + bias, per row: acc * rstd + (bias - mean * rstd * cvec)
+            const f32x4_t cv = *(const MIO_LDS f32x4_t*)((const MIO_LDS char*)(smem + G8_CVEC_OFF + wave * 256) + (16 * nt + 4 * g) * 4);
+            const f32x2_t cv01 = {cv[0], cv[1]}, cv23 = {cv[2], cv[3]};
+            const f32x2_t ta01 = (f32x2_t){a[0], a[1]} * rsA - mrA * cv01, ta23 = (f32x2_t){a[2], a[3]} * rsA - mrA * cv23;
+            const f32x2_t tb01 = (f32x2_t){b[0], b[1]} * rsB - mrB * cv01, tb23 = (f32x2_t){b[2], b[3]} * rsB - mrB * cv23;
+            a = (f32x4_t){ta01[0], ta01[1], ta23[0], ta23[1]};
+            b = (f32x4_t){tb01[0], tb01[1], tb23[0], tb23[1]};
+          }
           f32x2_t a01, a23, c01, c23;
           if constexpr (GLU) {
             const f32x4_t au = acc[2 * mtp][nt + 2], bu = acc[2 * mtp + 1][nt + 2];
@@ -332,13 +393,58 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
             c01 += (f32x2_t){(float)rb[0], (float)rb[1]};
             c23 += (f32x2_t){(float)rb[2], (float)rb[3]};
           }
-          const auto s0 = __builtin_amdgcn_permlane16_swap(pack2<T>(a01[0], a01[1]), pack2<T>(c01[0], c01[1]), false, false);
-          const auto s1 = __builtin_amdgcn_permlane16_swap(pack2<T>(a23[0], a23[1]), pack2<T>(c23[0], c23[1]), false, false);
+          const uint32_t pa01 = pack2<T>(a01[0], a01[1]), pa23 = pack2<T>(a23[0], a23[1]);
+          const uint32_t pc01 = pack2<T>(c01[0], c01[1]), pc23 = pack2<T>(c23[0], c23[1]);
+          if constexpr (FOLD == 2) {  // statistics of what is STORED (the rounded values), as a LayerNorm reading y would see them
+            using X2 = typename DT<T>::x2;
+            const X2 r0 = __builtin_bit_cast(X2, pa01), r1 = __builtin_bit_cast(X2, pa23);
+            const X2 r2 = __builtin_bit_cast(X2, pc01), r3 = __builtin_bit_cast(X2, pc23);
+            const float f0 = (float)r0[0], f1 = (float)r0[1], f2 = (float)r1[0], f3 = (float)r1[1];
+            const float h0 = (float)r2[0], h1 = (float)r2[1], h2 = (float)r3[0], h3 = (float)r3[1];
+            stA += (f0 + f1) + (f2 + f3);
+            sqA += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+            stB += (h0 + h1) + (h2 + h3);
+            sqB += (h0 * h0 + h1 * h1) + (h2 * h2 + h3 * h3);
+          }
+          const auto s0 = __builtin_amdgcn_permlane16_swap(pa01, pc01, false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(pa23, pc23, false, false);
           const u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
           keep[mtp * ONT + nt] = o;
           const bool ok = mok && (full || nt * 16 + 8 * (g >> 1) < onrem);
           const int off = ok ? yvo : 0x7fffffff;  // out of range: dropped by the buffer range check
           __builtin_amdgcn_raw_buffer_store_b128(o, yrs, off, mtp * ystep + (nt & 1) * 32 + (nt >> 1) * ychi, 0);
+        }
+        if constexpr (FOLD == 2) {
+          stA += __shfl_xor(stA, 16, 64); sqA += __shfl_xor(sqA, 16, 64); stB += __shfl_xor(stB, 16, 64); sqB += __shfl_xor(sqB, 16, 64);
+          stA += __shfl_xor(stA, 32, 64); sqA += __shfl_xor(sqA, 32, 64); stB += __shfl_xor(stB, 32, 64); sqB += __shfl_xor(sqB, 32, 64);
+          if (g == 0) {
+            MIO_LDS char* pl = (MIO_LDS char*)(smem + G8_STAT_OFF + grp * 8192 + wn * 1024) + (mtp * 32 + c16) * 8;
+            *(MIO_LDS f32x2_t*)pl = (f32x2_t){stA, sqA};
+            *(MIO_LDS f32x2_t*)(pl + 128) = (f32x2_t){stB, sqB};
+          }
+        }
+      }
+      if constexpr (FOLD == 2) {
+        // the last of the group's four column-quarter waves to get here adds the partials (fixed order) and stores the slot
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        MIO_LDS unsigned* cnt = (MIO_LDS unsigned*)(smem + G8_CNT_OFF) + grp;
+        unsigned old = 0;
+        if (ln == 0) old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == 3u) {
+          const MIO_LDS char* pb = (const MIO_LDS char*)(smem + G8_STAT_OFF + grp * 8192);
+          const int64_t mpad = (int64_t)p.tiles_m * 256;
+          float* dst = p.stats_out + ((int64_t)(on0 >> 8) * mpad + om0) * 2;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int r = ln + 64 * h;
+            f32x2_t t = *(const MIO_LDS f32x2_t*)(pb + r * 8);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) t += *(const MIO_LDS f32x2_t*)(pb + w * 1024 + r * 8);
+            *(f32x2_t*)(dst + 2 * r) = t;
+            asm volatile("s_nop 7" : : "v"(t) : "memory");  // (store data stays live behind the store, header note)
+          }
+          if (ln == 0) *cnt = 0u;
         }
       }
       // no register a store reads is written before the stores have fetched their data (header: store data must outlive ...)

@@ -4,6 +4,8 @@
 
 #include "gemm_kernel.h"
 
+constexpr int G8_LN_SLOTS_MAX_HOST = 8;  // gemm8w_kernel.h G8_LN_SLOTS_MAX (the kernel header is not included here)
+
 extern template int gemm_launch<__bf16>(GemmDev, int, hipStream_t);
 extern template int gemm_launch<_Float16>(GemmDev, int, hipStream_t);
 
@@ -51,6 +53,7 @@ extern "C" int mio_gemm_bias_act(const void* x, const void* w, const void* bias,
             "mio_gemm_bias_act: pointers must be 16-byte aligned");
   if (M == 0) return 0;
   GemmDev p;
+  gemm_dev_defaults(p);
   p.x = x; p.w = w; p.wg = w_gate; p.bias = bias; p.bias_g = bias_gate; p.res = residual; p.y = y;
   p.M = M; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldr = ldr; p.N = N; p.K = K;
   p.tiles_m = p.tiles_n = 0;
@@ -93,6 +96,7 @@ static int fused_mlp_impl(const void* x, const void* w1, const void* b1, const v
     MIO_CHECK(act != MIO_ACT_SWIGLU || wblk, "mio_fused_mlp_fwd: the gated 256-tile kernel takes the interleaved blocked weight "
                                             "(mio_weight_block_glu) through mio_fused_mlp_glu_fwd_bw");
     GemmDev p;
+    gemm_dev_defaults(p);
     p.x = x; p.w = w1; p.wg = nullptr; p.bias = b1; p.bias_g = bg; p.res = nullptr; p.y = workspace;
     p.M = M; p.ldx = d; p.ldw = d; p.ldy = I; p.ldr = 0; p.N = I; p.K = d;
     p.tiles_m = p.tiles_n = 0;
@@ -183,6 +187,7 @@ extern "C" int mio_gemm_bias_act_bw(const void* x, const void* wb, const void* b
   MIO_CHECK(gemm_blocked_w_ok(M, N, K, act), "mio_gemm_bias_act_bw: this shape does not take the blocked-weight kernels "
                                              "(mio_gemm_blocked_weight_ok == 0); use mio_gemm_bias_act with the plain weight");
   GemmDev p;
+  gemm_dev_defaults(p);
   p.x = x; p.w = wb; p.wg = nullptr; p.bias = bias; p.bias_g = nullptr; p.res = residual; p.y = y;
   p.M = M; p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.ldr = ldr; p.N = N; p.K = K;
   p.tiles_m = p.tiles_n = 0;
@@ -215,6 +220,7 @@ extern "C" int mio_gemm_bias_act_bw_cs(const void* x, const void* wb, const void
   MIO_CHECK(cs_lo >= 0 && cs_hi <= N && cs_lo % 128 == 0 && cs_hi % 128 == 0 && cs_lo <= cs_hi,
             "mio_gemm_bias_act_bw_cs: [cs_lo, cs_hi) must be multiples of 128 inside [0, N]");
   GemmDev p;
+  gemm_dev_defaults(p);
   p.x = x; p.w = wb; p.wg = nullptr; p.bias = bias; p.bias_g = nullptr; p.res = nullptr; p.y = y;
   p.M = M; p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.ldr = 0; p.N = N; p.K = K;
   p.tiles_m = p.tiles_n = 0;
@@ -280,4 +286,112 @@ extern "C" int mio_fused_mlp_glu_fwd_bw(const void* x, const void* wgu_b, const 
             "pass the plain weights to mio_fused_mlp_fwd");
   return fused_mlp_impl(x, wgu_b, b_up, nullptr, b_gate, w2b, b2, residual, y, workspace, M, d, I, MIO_ACT_SWIGLU, dtype, stream, 1,
                         x_blocked ? 1 : 0);
+}
+
+// ---- LayerNorm folded into the GEMMs on either side of it ------------------------------------------------
+// Reference: kernels/triton/fused_layernorm_qkv.py:37-420 (LayerNorm as the prologue of the QKV projection) and
+// layernorm_kernels.py:35-188 (residual add + LayerNorm in one pass).  Here neither a prologue nor a pass: the GEMM that
+// WRITES the residual stream (out-proj / fc2, residual epilogue) also writes each output row's (sum, sum of squares) per
+// 256-column tile, and the projection BEHIND the LayerNorm multiplies the raw stream with gamma-scaled weights and applies
+// mean / rstd in its read-out:  LN(x) W^T + b = rstd * (x W'^T - mean * c) + b',  W' = gamma o W, c = W' 1, b' = b + W beta.
+extern "C" size_t mio_ln_stats_bytes(int64_t M, int32_t width) {
+  return (size_t)((width + 255) / 256) * (size_t)((M + 255) / 256 * 256) * 2 * sizeof(float);
+}
+
+extern "C" int32_t mio_gemm_ln_ok(int64_t M, int32_t N, int32_t K, int32_t act, int32_t fold_in, int32_t stats_out) {
+  if (mio_gemm_impl() != 0) return 0;
+  if (!gemm_blocked_w_ok(M, N, K, act) || N % 32 != 0) return 0;
+  if (fold_in && (K % 256 != 0 || K / 256 > G8_LN_SLOTS_MAX_HOST || (act != MIO_ACT_NONE && act != MIO_ACT_GELU_TANH))) return 0;
+  if (stats_out && (N % 256 != 0 || N / 256 > G8_LN_SLOTS_MAX_HOST || act != MIO_ACT_NONE || fold_in)) return 0;
+  return 1;
+}
+
+// one workgroup per weight row: w_scaled[n][k] = T(w[n][k] * gamma[k]), cvec[n] = sum_k w_scaled[n][k] (of the ROUNDED
+// products: what the matrix core multiplies), bias_out[n] = T(bias[n] + sum_k w[n][k] * beta[k])
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fold_weight_kernel(const T* __restrict__ w, int64_t ldw, const T* __restrict__ gamma,
+                                                             const T* __restrict__ beta, const T* __restrict__ bias,
+                                                             T* __restrict__ ws, float* __restrict__ cvec, T* __restrict__ bias_out,
+                                                             int K) {
+  __shared__ float s_c[256], s_b[256];
+  const int n = blockIdx.x, t = threadIdx.x;
+  float c = 0.f, bb = 0.f;
+  for (int k = t; k < K; k += 256) {
+    const float wv = (float)w[(int64_t)n * ldw + k];
+    const T r = (T)(wv * (float)gamma[k]);
+    ws[(int64_t)n * K + k] = r;
+    c += (float)r;
+    if (beta != nullptr) bb += wv * (float)beta[k];
+  }
+  s_c[t] = c;
+  s_b[t] = bb;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) {
+      s_c[t] += s_c[t + s];
+      s_b[t] += s_b[t + s];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    cvec[n] = s_c[0];
+    bias_out[n] = (T)((bias != nullptr ? (float)bias[n] : 0.f) + s_b[0]);
+  }
+}
+
+extern "C" int mio_ln_fold_weight(const void* w, int64_t ldw, const void* gamma, const void* beta, const void* bias,
+                                  void* w_scaled, float* cvec, void* bias_out, int32_t N, int32_t K, int32_t dtype, void* stream) {
+  MIO_CHECK(w && gamma && w_scaled && cvec && bias_out, "mio_ln_fold_weight: w, gamma, w_scaled, cvec, bias_out must be non-null");
+  MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_ln_fold_weight: dtype must be bf16 or fp16");
+  MIO_CHECK(N > 0 && K > 0 && ldw >= K, "mio_ln_fold_weight: bad sizes");
+  if (dtype == MIO_BF16)
+    hipLaunchKernelGGL(ln_fold_weight_kernel<__bf16>, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, (const __bf16*)w, ldw,
+                       (const __bf16*)gamma, (const __bf16*)beta, (const __bf16*)bias, (__bf16*)w_scaled, cvec, (__bf16*)bias_out, K);
+  else
+    hipLaunchKernelGGL(ln_fold_weight_kernel<_Float16>, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)w, ldw,
+                       (const _Float16*)gamma, (const _Float16*)beta, (const _Float16*)bias, (_Float16*)w_scaled, cvec,
+                       (_Float16*)bias_out, K);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("mio_ln_fold_weight launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, const void* residual, void* y, int64_t M, int32_t N,
+                              int32_t K, int64_t ldx, int64_t ldy, int64_t ldr, int32_t act, int32_t dtype, int32_t flags,
+                              const float* ln_stats, const float* ln_cvec, float ln_eps, float* stats_out, int32_t cs_lo,
+                              int32_t cs_hi, float cs_val, void* stream) {
+  const bool xb = (flags & MIO_GEMM_X_BLOCKED) != 0, yb = (flags & MIO_GEMM_Y_BLOCKED) != 0, rb = (flags & MIO_GEMM_RES_BLOCKED) != 0;
+  MIO_CHECK(x && wb && y, "mio_gemm_ln_bw: x, wb, y must be non-null");
+  MIO_CHECK(M > 0 && N > 0 && K > 0, "mio_gemm_ln_bw: bad sizes");
+  MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_gemm_ln_bw: dtype must be bf16 or fp16");
+  MIO_CHECK(act >= MIO_ACT_NONE && act < MIO_ACT_SWIGLU, "mio_gemm_ln_bw: unknown / unsupported activation");
+  MIO_CHECK((flags & ~7) == 0, "mio_gemm_ln_bw: unknown flag");
+  MIO_CHECK((ln_stats == nullptr) == (ln_cvec == nullptr), "mio_gemm_ln_bw: ln_stats and ln_cvec come together");
+  MIO_CHECK(mio_gemm_ln_ok(M, N, K, act, ln_stats != nullptr, stats_out != nullptr),
+            "mio_gemm_ln_bw: this shape / activation does not take the folded kernels (mio_gemm_ln_ok == 0)");
+  MIO_CHECK(ln_stats == nullptr || residual == nullptr, "mio_gemm_ln_bw: the consumer form takes no residual");
+  MIO_CHECK(stats_out == nullptr || residual != nullptr, "mio_gemm_ln_bw: the producer form is the residual epilogue");
+  MIO_CHECK(!rb || residual != nullptr, "mio_gemm_ln_bw: RES_BLOCKED without a residual");
+  if (xb) ldx = K;
+  if (yb) ldy = N;
+  if (rb) ldr = N;
+  MIO_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && (residual == nullptr || ldr % 8 == 0) && ldx >= K && ldy >= N &&
+                (residual == nullptr || ldr >= N),
+            "mio_gemm_ln_bw: bad strides");
+  MIO_CHECK(ldx * 512 < (int64_t)0x7fffffff && ldy * 512 < (int64_t)0x7fffffff && (residual == nullptr || ldr * 512 < (int64_t)0x7fffffff),
+            "mio_gemm_ln_bw: row stride too large");
+  MIO_CHECK(mio_aligned16(x) && mio_aligned16(wb) && mio_aligned16(y) && mio_aligned16(residual) && mio_aligned16(bias) &&
+                mio_aligned16(ln_stats) && mio_aligned16(ln_cvec) && mio_aligned16(stats_out),
+            "mio_gemm_ln_bw: pointers must be 16-byte aligned");
+  MIO_CHECK(cs_lo >= cs_hi || (residual == nullptr && cs_lo >= 0 && cs_hi <= N && cs_lo % 128 == 0 && cs_hi % 128 == 0),
+            "mio_gemm_ln_bw: [cs_lo, cs_hi) must be multiples of 128 inside [0, N], without a residual");
+  GemmDev p;
+  gemm_dev_defaults(p);
+  p.x = x; p.w = wb; p.bias = bias; p.res = residual; p.y = y;
+  p.M = M; p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.ldr = ldr; p.N = N; p.K = K;
+  p.x_blk = xb ? 1 : 0; p.y_blk = yb ? 1 : 0; p.w_blk = 1; p.res_blk = rb ? 1 : 0;
+  p.cs_lo = cs_lo; p.cs_hi = cs_hi; p.cs_val = cs_val;
+  p.ln_stats = ln_stats; p.ln_cvec = ln_cvec; p.ln_eps = ln_eps; p.ln_slots = ln_stats ? K / 256 : 0;
+  p.stats_out = stats_out;
+  return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
 }

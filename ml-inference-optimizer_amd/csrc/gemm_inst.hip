@@ -117,12 +117,13 @@ static int launch_4w16p(GemmDev p, hipStream_t stream) {
 #endif  // MIO_DIAG
 
 // eight-wave ping-pong kernel (gemm8w_kernel.h), persistent; `one_tile`: one workgroup per tile instead (A/B only)
-template <int ACT, bool RES, int VAR = 0>
+template <int ACT, bool RES, int VAR = 0, int FOLD = 0>
 static int launch_8w(GemmDev p, hipStream_t stream, bool one_tile = false) {
   constexpr int BN = (ACT == MIO_ACT_SWIGLU) ? 128 : 256;
+  constexpr int G8_SMEM = FOLD ? G8_SMEM_FOLD : ::G8_SMEM;  // (shadows the namespace-scope constant for this launcher)
   p.tiles_m = (int)((p.M + 255) / 256);
   p.tiles_n = (p.N + BN - 1) / BN;
-  auto kern = gemm8w_kernel<GT, ACT, RES, VAR>;
+  auto kern = gemm8w_kernel<GT, ACT, RES, VAR, FOLD>;
   static std::once_flag once;
   static hipError_t ea = hipSuccess;
   static int ncu = 256;
@@ -172,6 +173,13 @@ static int launch_act(const GemmDev& p, hipStream_t stream) {
                         (p.ldw * 512 < (int64_t)0x7fffffff) && (p.ldy * 512 < (int64_t)0x7fffffff) &&
                         (p.res == nullptr || p.ldr * 512 < (int64_t)0x7fffffff);
       if (!fits) return launch_cfg<256, 256, 2, 4, ACT>(p, stream);
+      // LayerNorm fold (mio_gemm_ln_bw checked the shape): consumer = projection behind the LayerNorm, producer = residual GEMM
+      if constexpr (ACT == MIO_ACT_NONE || ACT == MIO_ACT_GELU_TANH) {
+        if (p.ln_stats != nullptr) return launch_8w<ACT, false, 0, 1>(p, stream);
+      }
+      if constexpr (ACT == MIO_ACT_NONE) {
+        if (p.stats_out != nullptr) return launch_8w<ACT, true, 0, 2>(p, stream);
+      }
 #ifdef MIO_DIAG
       if constexpr (ACT == MIO_ACT_NONE) {
         if (gemm_impl() == 8 && p.dbg != nullptr) return launch_8w<ACT, false, 128>(p, stream);  // stamps

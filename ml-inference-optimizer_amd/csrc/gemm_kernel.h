@@ -44,7 +44,28 @@ struct GemmDev {
   int cs_lo, cs_hi;
   float cs_val;
   int group_m;  // row tiles that share each weight tile inside an XCD's run of tiles (0: the default 8)
+  // LayerNorm folded into the GEMMs on either side of it (gemm8w_kernel FOLD, mio_gemm_ln_bw; reference
+  // kernels/triton/fused_layernorm_qkv.py:37-420, layernorm_kernels.py:35-188):
+  //   producer (the GEMM that writes the residual stream, FOLD = 2): stats_out[slot][row] = (sum, sum of squares) of the ROUNDED
+  //     output row over the tile column `slot` (N / 256 slots, rows padded to whole 256-row tiles);
+  //   consumer (the projection behind the LayerNorm, FOLD = 1): w holds gamma-scaled weights, bias the beta-folded bias,
+  //     ln_cvec[n] = sum_k w'[n][k]; the read-out computes (acc - mean * cvec) * rstd + bias from ln_stats (ln_slots slots).
+  int res_blk;             // the residual is in the blocked activation layout (width N)
+  const float* ln_stats;   // consumer: [ln_slots][tiles_m * 256][2]
+  const float* ln_cvec;    // consumer: [N]
+  float* stats_out;        // producer: [N / 256][tiles_m * 256][2]
+  int ln_slots;
+  float ln_eps;
 };
+
+static inline void gemm_dev_defaults(GemmDev& p) {
+  p.wg = nullptr; p.bias = nullptr; p.bias_g = nullptr; p.res = nullptr;
+  p.tiles_m = p.tiles_n = 0;
+  p.x_blk = p.y_blk = p.w_blk = 0;
+  p.dbg = nullptr;
+  p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f; p.group_m = 0;
+  p.res_blk = 0; p.ln_stats = nullptr; p.ln_cvec = nullptr; p.stats_out = nullptr; p.ln_slots = 0; p.ln_eps = 0.f;
+}
 
 int mio_gemm_impl();  // MIO_GEMM_IMPL override (0 = default dispatch); defined in gemm_api.hip
 

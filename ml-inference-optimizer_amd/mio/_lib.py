@@ -46,6 +46,10 @@ EXPORTS = (
     "mio_weight_block_glu",
     "mio_fused_mlp_glu_fwd_bw",
     "mio_layernorm_fwd_bx",
+    "mio_ln_stats_bytes",
+    "mio_gemm_ln_ok",
+    "mio_ln_fold_weight",
+    "mio_gemm_ln_bw",
     "mio_layernorm_fwd",
     "mio_fa3_decode_workspace_bytes",
     "mio_fa3_decode_paged",
@@ -136,6 +140,14 @@ def _load() -> C.CDLL:
     lib.mio_weight_block_glu.restype = i32
     lib.mio_fused_mlp_glu_fwd_bw.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
     lib.mio_fused_mlp_glu_fwd_bw.restype = i32
+    lib.mio_ln_stats_bytes.argtypes = [i64, i32]
+    lib.mio_ln_stats_bytes.restype = C.c_size_t
+    lib.mio_gemm_ln_ok.argtypes = [i64, i32, i32, i32, i32, i32]
+    lib.mio_gemm_ln_ok.restype = i32
+    lib.mio_ln_fold_weight.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.mio_ln_fold_weight.restype = i32
+    lib.mio_gemm_ln_bw.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i32, i32, i32, vp, vp, f32, vp, i32, i32, f32, vp]
+    lib.mio_gemm_ln_bw.restype = i32
     lib.mio_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]
     lib.mio_layernorm_fwd.restype = i32
     lib.mio_layernorm_fwd_bx.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]

@@ -685,6 +685,80 @@ def test_paged_decode_gqa_long_contexts(dtype, D, H, Hkv, q_len, bs):
     assert torch.equal(view, out) and big[..., D:].abs().max() == 0
 
 
+def _unblock(t, M, N):
+    """Blocked activation layout [ceil(M/256), N/32, 256, 32] -> row-major [M, N]."""
+    mp = (M + 255) // 256 * 256
+    return t.view(mp // 256, N // 32, 256, 32).permute(0, 2, 1, 3).reshape(mp, N)[:M]
+
+
+def _block(t):
+    M, N = t.shape
+    mp = (M + 255) // 256 * 256
+    pad = torch.zeros(mp, N, dtype=t.dtype, device=t.device)
+    pad[:M] = t
+    return pad.view(mp // 256, 256, N // 32, 32).permute(0, 2, 1, 3).contiguous().view(mp, N)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("act", ["none", "gelu"])
+def test_gemm_ln_fold(dtype, act):
+    """LayerNorm folded into the GEMMs on either side of it (mio_gemm_ln_bw): the residual GEMM writes its output blocked +
+    the rows' (sum, sum of squares); the projection behind the LayerNorm runs on the raw stream with gamma-scaled weights.
+    M 16 500 (ragged last row tile), d 1024 (4 statistic slots), against the oracle's LayerNorm -> linear and, where the
+    arithmetic is the same, bit for bit against the unfused kernels."""
+    ops = _ops()
+    torch.manual_seed(11)
+    M, d, N2 = 16500, 1024, 2048
+    assert ops.gemm_ln_ok(M, d, d, "none", stats_out=True) and ops.gemm_ln_ok(M, N2, d, act, fold_in=True)
+    x0 = torch.randn(M, d).to(dtype)
+    r0 = (torch.randn(M, d) * 2 + 0.3).to(dtype)   # a residual stream with a mean
+    wp = (torch.randn(d, d) * 0.03).to(dtype)
+    bp = (torch.randn(d) * 0.1).to(dtype)
+    gamma, beta = (1 + 0.2 * torch.randn(d)).to(dtype), (0.1 * torch.randn(d)).to(dtype)
+    wc = (torch.randn(N2, d) * 0.03).to(dtype)
+    bc = (torch.randn(N2) * 0.1).to(dtype)
+    x0d, r0d, wpd, bpd, gd, btd, wcd, bcd = (t.to(DEV) for t in (x0, r0, wp, bp, gamma, beta, wc, bc))
+    wpb = ops.block_weight(wpd)
+    # -- producer: y = x0 wp^T + bp + r0, blocked, + statistics
+    yb, st = ops.gemm_ln(x0d, wpb, bpd, M=M, N=d, K=d, residual=r0d, out_blocked=True, stats_out=True)
+    y_plain = ops.gemm_bias_act(x0d, wpd, bpd, residual=r0d, w_blocked=wpb)
+    y = _unblock(yb, M, d)
+    assert torch.equal(y, y_plain)
+    assert tuple(st.shape) == (d // 256, (M + 255) // 256 * 256, 2)
+    yf = y.float().view(M, d // 256, 256)
+    want_s, want_q = yf.sum(-1).t(), (yf * yf).sum(-1).t()
+    assert torch.allclose(st[:, :M, 0], want_s, rtol=1e-4, atol=1e-3) and torch.allclose(st[:, :M, 1], want_q, rtol=1e-4, atol=1e-3)
+    yb2, st2 = ops.gemm_ln(x0d, wpb, bpd, M=M, N=d, K=d, residual=r0d, out_blocked=True, stats_out=True)
+    assert torch.equal(st2[:, :M], st[:, :M]) and torch.equal(_unblock(yb2, M, d), y)   # deterministic (rows past M are never written)
+    # -- consumer: z = act(LN(y) wc^T + bc) on the raw blocked stream
+    wfb, cvec, bfold = ops.ln_fold_weight(wcd, gd, btd, bcd)
+    zb, none = ops.gemm_ln(yb, wfb, bfold, M=M, N=N2, K=d, activation=act, x_blocked=True, out_blocked=True,
+                           ln_stats=st, ln_cvec=cvec, eps=1e-5)
+    assert none is None
+    z = _unblock(zb, M, N2)
+    rows = torch.cat([torch.arange(0, M, 61), torch.tensor([255, 256, 16383, 16384, M - 1])])
+    yc = y[rows].cpu()
+    ln = oracle.layernorm(yc, gamma, beta, 1e-5)          # fp64 LayerNorm of the stored stream (not rounded to 16 bits)
+    want = ln.double() @ wc.double().t() + bc.double()
+    if act == "gelu":
+        want = torch.nn.functional.gelu(want, approximate="tanh")
+    _cmp(z[rows], want, dtype, f"ln-fold consumer {act}")
+    # the same through row-major operands (x row-major, y row-major)
+    z2, _ = ops.gemm_ln(y, wfb, bfold, M=M, N=N2, K=d, activation=act, ln_stats=st, ln_cvec=cvec)
+    assert torch.equal(z2, z)
+    # column scale on the folded read-out (the K columns of a QKV projection)
+    z3, _ = ops.gemm_ln(yb, wfb, bfold, M=M, N=N2, K=d, activation=act, x_blocked=True, ln_stats=st, ln_cvec=cvec,
+                        col_scale=(1024, 2048, 0.25))
+    assert torch.equal(z3[:, :1024], z[:, :1024])
+    _cmp(z3[rows][:, 1024:], want[:, 1024:] * 0.25, dtype, "ln-fold consumer + col_scale")
+    # -- a second residual GEMM reading the BLOCKED stream as its residual, row-major output, no statistics
+    w2 = (torch.randn(d, N2) * 0.02).to(dtype).to(DEV)
+    w2b = ops.block_weight(w2)
+    o_blk, _ = ops.gemm_ln(zb, w2b, bpd, M=M, N=d, K=N2, x_blocked=True, residual=yb, res_blocked=True)
+    o_plain = ops.gemm_bias_act(z, w2, bpd, residual=y, w_blocked=w2b)
+    assert torch.equal(o_blk, o_plain)
+
+
 def test_errors_raise_before_launch():
     ops = _ops()
     q = torch.randn(1, 8, 2, 64, dtype=torch.float16, device=DEV)

@@ -18,7 +18,7 @@ def test_cabi_exports_match_header():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(_lib.lib, name), name
-    assert _lib.lib.mio_version() == 103
+    assert _lib.lib.mio_version() == 104
     assert _lib.lib.mio_last_error() is not None  # callable without a GPU
 
 
