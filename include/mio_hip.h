@@ -188,9 +188,12 @@ int mio_layernorm_fwd_bx(const void* x, const void* residual, const void* weight
  *   producer = the GEMM that writes the residual stream (out-proj / fc2 with the residual epilogue): stats_out != NULL makes it
  *     also write, per output row and 256-column tile, (sum, sum of squares) of the ROUNDED row: [N / 256][ceil(M/256)*256][2]
  *     fp32 (mio_ln_stats_bytes(M, N)); deterministic (fixed summation order, no atomics);
- *   consumer = the projection behind the LayerNorm: ln_stats (a producer's stats_out of width K) + ln_cvec != NULL: x is the raw
- *     stream, wb = mio_weight_block of the gamma-scaled weight, bias the beta-folded bias, ln_cvec[n] = sum_k w'[n][k]
- *     (all three from mio_ln_fold_weight); the read-out computes rstd * (x w'^T - mean * cvec) + bias, then act / column scale.
+ *   consumer = the projection behind the LayerNorm: ln_stats (a producer's stats_out of width K) != NULL: x is the raw stream,
+ *     wb = mio_weight_block of the gamma-scaled, row-centred weight and bias the beta-folded bias (both from mio_ln_fold_weight:
+ *     (x - mean 1) . w = x . (w - mean(w) 1), so centring the weight rows makes the plain product the centred one); the
+ *     read-out computes rstd * acc + bias, then act / column scale.  Rounding: the centred weights' row sums are zero only up to
+ *     their 16-bit rounding, which leaves an error of about (|mean| / std) * 1e-3 of the output -- the size of one more 16-bit
+ *     rounding for a stream whose row mean is as large as its row deviation.
  * flags: the operands in the blocked activation layout ((256-row, 32-column) blocks of 16 KiB, rows padded to 256; ld* ignored
  * for a blocked operand): x (as mio_gemm_bias_act_bw's x_blocked), y (what the next GEMM takes as blocked x), residual.
  * Shapes: mio_gemm_ln_ok(M, N, K, act, fold_in, stats_out) != 0 (blocked-weight shapes; fold_in: K % 256 == 0, K <= 2048, act
@@ -202,12 +205,12 @@ int mio_layernorm_fwd_bx(const void* x, const void* residual, const void* weight
 size_t mio_ln_stats_bytes(int64_t M, int32_t width);
 int32_t mio_gemm_ln_ok(int64_t M, int32_t N, int32_t K, int32_t act, int32_t fold_in, int32_t stats_out);
 /* w [N, K] (row stride ldw), gamma / beta [K] (beta nullable), bias [N] (nullable), all in dtype; w_scaled [N, K] contiguous
- * = w * gamma (rounded once), cvec [N] fp32 = row sums of w_scaled, bias_out [N] = bias + w beta.  One-time weight preparation. */
+ * = w * gamma - mean_k(w * gamma) (rounded once), bias_out [N] = bias + w beta.  One-time weight preparation. */
 int mio_ln_fold_weight(const void* w, int64_t ldw, const void* gamma, const void* beta, const void* bias, void* w_scaled,
-                       float* cvec, void* bias_out, int32_t N, int32_t K, int32_t dtype, void* stream);
+                       void* bias_out, int32_t N, int32_t K, int32_t dtype, void* stream);
 int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, const void* residual, void* y, int64_t M, int32_t N, int32_t K,
                    int64_t ldx, int64_t ldy, int64_t ldr, int32_t act, int32_t dtype, int32_t flags, const float* ln_stats,
-                   const float* ln_cvec, float ln_eps, float* stats_out, int32_t cs_lo, int32_t cs_hi, float cs_val, void* stream);
+                   float ln_eps, float* stats_out, int32_t cs_lo, int32_t cs_hi, float cs_val, void* stream);
 
 /* LayerNorm / residual+LayerNorm rows (the step either side of attention):
  * sum = x + alpha*residual (if residual), y = (sum-mean)/sqrt(var+eps)*weight + bias.

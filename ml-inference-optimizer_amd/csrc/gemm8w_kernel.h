@@ -58,10 +58,10 @@
 constexpr int G8_THREADS = 512;
 constexpr int G8_BIAS_OFF = G6_SMEM;  // 8 waves x 256 B: each wave's slice of the bias row(s)
 constexpr int G8_SMEM = G6_SMEM + 8 * 256;
-// LayerNorm fold (FOLD != 0): per-wave fp32 column-vector slot, the row-statistics region (consumer: [group][slot <= 8][128 rows]
+// LayerNorm fold (FOLD != 0): per-wave rstd table, the row-statistics region (consumer: [group][slot <= 8][128 rows]
 // (sum, sum of squares); producer: [group][column quarter][128 rows]) and the producer's arrival counters
-constexpr int G8_CVEC_OFF = G8_SMEM;
-constexpr int G8_STAT_OFF = G8_CVEC_OFF + 8 * 256;
+constexpr int G8_RS_OFF = G8_SMEM;  // consumer: per wave, rstd of its group's 128 rows (512 B)
+constexpr int G8_STAT_OFF = G8_RS_OFF + 8 * 512;
 constexpr int G8_CNT_OFF = G8_STAT_OFF + 2 * 8192;
 constexpr int G8_SMEM_FOLD = G8_CNT_OFF + 64;
 constexpr int G8_LN_SLOTS_MAX = 8;
@@ -69,8 +69,8 @@ constexpr int G8_LN_SLOTS_MAX = 8;
 // VAR (timing-only ablations, diagnostic library): 4 = no prefetch issue in the loop, 16 = no counted wait,
 // 64 = every piece re-reads K-tile 0, 128 = in-kernel stamps (tools/gemm8_stamps.py), 256 = scalar activation math,
 // 2048 = all eight activation fragments read in the read segment
-// FOLD (GemmDev, "LayerNorm folded into the GEMMs on either side of it"): 1 = consumer (the read-out normalises: (acc - mean *
-// cvec) * rstd + bias, row statistics from p.ln_stats), 2 = producer (the read-out also writes the rounded output rows' (sum, sum
+// FOLD (GemmDev, "LayerNorm folded into the GEMMs on either side of it"): 1 = consumer (the weights are centred, so the read-out
+// normalises with acc * rstd + bias; row statistics from p.ln_stats), 2 = producer (the read-out also writes the rounded output rows' (sum, sum
 // of squares) per tile column: the four column-quarter waves of a group leave their partials in LDS, the last one to arrive adds
 // them in a fixed order -- deterministic -- and stores 128 rows x 8 bytes)
 template <typename T, int ACT, bool RES, int VAR = 0, int FOLD = 0>
@@ -228,6 +228,23 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
     }
     // K-tiles 0 .. nk-4 prefetch inside this tile (nk >= 4)
     ktile(0, 3, IC(1), IC(0));
+    if constexpr (FOLD == 1) {
+      // row statistics of the group's 128 rows of THIS tile (wave wn requests rows 32 wn .. 32 wn + 31 of every slot: 256
+      // contiguous bytes per slot), requested behind K-tile 0: every wave has left the previous tile's read-out (K-tile 0's
+      // barriers), so the statistics region is free, and the requests are old by the time the tail's counted waits need them
+      // gone -- issued in front of the tail they cost every tile one memory latency.  K-tile 1's vmcnt(8) then also waits for
+      // K-tile 3 (issued before these): once per tile, beside the wait for the previous tile's stores that sits there anyway.
+      const int l = lane_now();
+      const int64_t fm0 = m0 + grp * 128;
+      const int64_t mpad = (int64_t)p.tiles_m * 256;
+      const float* ssrc = p.ln_stats + (fm0 + 32 * wn) * 2 + l;
+      const uint32_t slds = (uint32_t)(size_t)((MIO_LDS char*)(smem + G8_STAT_OFF + grp * 8192 + wn * 256));
+      for (int s = 0; s < p.ln_slots; ++s) {
+        const float* src = ssrc + (int64_t)s * mpad * 2;
+        const uint32_t dst = slds + s * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
+      }
+    }
     if constexpr ((VAR & 128) != 0) st[1] = __builtin_amdgcn_s_memtime();
     for (int kt = 1; kt < nk - 3; ++kt) ktile(kt, kt + 3, IC(0), IC(8));
     if constexpr ((VAR & 128) != 0) st[3] = __builtin_amdgcn_s_memtime();
@@ -254,23 +271,6 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
       const T* src = base + nc;
       const uint32_t lds = (uint32_t)(size_t)((MIO_LDS char*)(smem + G8_BIAS_OFF + wave * 256));
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(lds), "v"(src) : "memory", "m0");
-    }
-    if constexpr (FOLD == 1) {
-      // column vector (this wave's 64 columns, fp32) and the row statistics of the group's 128 rows (wave wn requests rows
-      // 32 wn .. 32 wn + 31 of every slot: 256 contiguous bytes per slot).  Older than the tail's loads like the bias request;
-      // the statistics are read by the group's other waves too: the tail's barriers stand between these waits and the read-out.
-      const int l = lane_now();
-      const float* csrc = p.ln_cvec + (on0 + l < p.N ? on0 + l : p.N - 1);
-      const uint32_t clds = (uint32_t)(size_t)((MIO_LDS char*)(smem + G8_CVEC_OFF + wave * 256));
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(clds), "v"(csrc) : "memory", "m0");
-      const int64_t mpad = (int64_t)p.tiles_m * 256;
-      const float* ssrc = p.ln_stats + (om0 + 32 * wn) * 2 + l;
-      const uint32_t slds = (uint32_t)(size_t)((MIO_LDS char*)(smem + G8_STAT_OFF + grp * 8192 + wn * 256));
-      for (int s = 0; s < p.ln_slots; ++s) {
-        const float* src = ssrc + (int64_t)s * mpad * 2;
-        const uint32_t dst = slds + s * 1024;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
-      }
     }
     const int next = tile + (int)gridDim.x;
     const bool has_next = next < ntiles;
@@ -325,6 +325,30 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
       }
       const int rchi = (RES && p.res_blk) ? 16384 : 64;   // bytes from column tile nt to nt + 2 of the residual
       const int rrow = (RES && p.res_blk) ? 64 : (int)p.ldr * 2;  // bytes per residual row
+      // FOLD 1: rstd of this lane's eight rows (16 r + c16).  The weights are centred (mio_ln_fold_weight: every row of gamma o W
+      // has its mean over k subtracted), so x . w'^T already equals (x - mean) . (gamma o W)^T and the read-out is acc * rstd +
+      // bias: one packed fma where the plain kernel has a packed add.  Each wave turns the slots' (sum, sum of squares) of its
+      // group's 128 rows into rstd once (two rows per lane) in its private table and reads back the eight it needs.
+      float rsv[8];
+      if constexpr (FOLD == 1) {
+        const MIO_LDS char* sl = (const MIO_LDS char*)(smem + G8_STAT_OFF + grp * 8192);
+        MIO_LDS float* mine = (MIO_LDS float*)(smem + G8_RS_OFF + wave * 512);
+        const float ik = 1.f / (float)p.K;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = ln + 64 * h;
+          float sm = 0.f, sq = 0.f;
+          for (int s = 0; s < p.ln_slots; ++s) {
+            const f32x2_t v = *(const MIO_LDS f32x2_t*)(sl + s * 1024 + r * 8);
+            sm += v[0];
+            sq += v[1];
+          }
+          const float mu = sm * ik;
+          mine[r] = __builtin_amdgcn_rsqf(fmaxf(sq * ik - mu * mu, 0.f) + p.ln_eps);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) rsv[r] = mine[16 * r + c16];
+      }
       u32x4_t keep[NCH];
 #pragma unroll
       for (int mtp = 0; mtp < 4; ++mtp) {
@@ -341,35 +365,29 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
           }
         }
         const bool mok = full || (mtp * 32 + rS < omrem);
-        // FOLD 1: rstd and mean * rstd of this lane's two rows (32 mtp + c16 and + 16) from the slots' (sum, sum of squares)
-        f32x2_t rsA = {1.f, 1.f}, rsB = {1.f, 1.f}, mrA = {0.f, 0.f}, mrB = {0.f, 0.f};
+        f32x2_t rsA = {1.f, 1.f}, rsB = {1.f, 1.f};
         if constexpr (FOLD == 1) {
-          const MIO_LDS char* sl = (const MIO_LDS char*)(smem + G8_STAT_OFF + grp * 8192) + (mtp * 32 + c16) * 8;
-          float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
-          for (int s = 0; s < p.ln_slots; ++s) {
-            const f32x2_t va = *(const MIO_LDS f32x2_t*)(sl + s * 1024), vb = *(const MIO_LDS f32x2_t*)(sl + s * 1024 + 128);
-            sa += va[0]; qa += va[1]; sb += vb[0]; qb += vb[1];
-          }
-          const float ik = 1.f / (float)p.K;
-          const float ma = sa * ik, mb = sb * ik;
-          const float ra = __builtin_amdgcn_rsqf(fmaxf(qa * ik - ma * ma, 0.f) + p.ln_eps);
-          const float rb = __builtin_amdgcn_rsqf(fmaxf(qb * ik - mb * mb, 0.f) + p.ln_eps);
-          rsA = (f32x2_t){ra, ra}; rsB = (f32x2_t){rb, rb};
-          mrA = (f32x2_t){ma * ra, ma * ra}; mrB = (f32x2_t){mb * rb, mb * rb};
+          rsA = (f32x2_t){rsv[2 * mtp], rsv[2 * mtp]};
+          rsB = (f32x2_t){rsv[2 * mtp + 1], rsv[2 * mtp + 1]};
         }
         float stA = 0.f, sqA = 0.f, stB = 0.f, sqB = 0.f;  // FOLD 2: this lane's share of the two rows' (sum, sum of squares)
 #pragma unroll
         for (int nt = 0; nt < ONT; ++nt) {
-          f32x4_t a = acc[2 * mtp][nt], b = acc[2 * mtp + 1][nt];
+          const f32x4_t a = acc[2 * mtp][nt], b = acc[2 * mtp + 1][nt];
           const X4 bv = __builtin_bit_cast(X4, bq[nt]);
-          f32x2_t b01 = {(float)bv[0], (float)bv[1]}, b23 = {(float)bv[2], (float)bv[3]};
-          if constexpr (FOLD == 1) {  // (acc - mean * cvec) * rstd + bias, per row: acc * rstd + (bias - mean * rstd * cvec)
-            const f32x4_t cv = *(const MIO_LDS f32x4_t*)((const MIO_LDS char*)(smem + G8_CVEC_OFF + wave * 256) + (16 * nt + 4 * g) * 4);
-            const f32x2_t cv01 = {cv[0], cv[1]}, cv23 = {cv[2], cv[3]};
-            const f32x2_t ta01 = (f32x2_t){a[0], a[1]} * rsA - mrA * cv01, ta23 = (f32x2_t){a[2], a[3]} * rsA - mrA * cv23;
-            const f32x2_t tb01 = (f32x2_t){b[0], b[1]} * rsB - mrB * cv01, tb23 = (f32x2_t){b[2], b[3]} * rsB - mrB * cv23;
-            a = (f32x4_t){ta01[0], ta01[1], ta23[0], ta23[1]};
-            b = (f32x4_t){tb01[0], tb01[1], tb23[0], tb23[1]};
+          const f32x2_t b01 = {(float)bv[0], (float)bv[1]}, b23 = {(float)bv[2], (float)bv[3]};
+          // pre-activation value of rows A / B: acc + bias, or (FOLD 1) acc * rstd + bias
+          f32x2_t va01, va23, vb01, vb23;
+          if constexpr (FOLD == 1) {
+            va01 = (f32x2_t){a[0], a[1]} * rsA + b01;
+            va23 = (f32x2_t){a[2], a[3]} * rsA + b23;
+            vb01 = (f32x2_t){b[0], b[1]} * rsB + b01;
+            vb23 = (f32x2_t){b[2], b[3]} * rsB + b23;
+          } else {
+            va01 = (f32x2_t){a[0], a[1]} + b01;
+            va23 = (f32x2_t){a[2], a[3]} + b23;
+            vb01 = (f32x2_t){b[0], b[1]} + b01;
+            vb23 = (f32x2_t){b[2], b[3]} + b23;
           }
           f32x2_t a01, a23, c01, c23;
           if constexpr (GLU) {
@@ -381,10 +399,10 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
             c01 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>((f32x2_t){b[0], b[1]} + b01) * ((f32x2_t){bu[0], bu[1]} + u01);
             c23 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>((f32x2_t){b[2], b[3]} + b23) * ((f32x2_t){bu[2], bu[3]} + u23);
           } else {
-            a01 = gemm_act2<ACT, SCALAR_ACT>((f32x2_t){a[0], a[1]} + b01) * cs2;
-            a23 = gemm_act2<ACT, SCALAR_ACT>((f32x2_t){a[2], a[3]} + b23) * cs2;
-            c01 = gemm_act2<ACT, SCALAR_ACT>((f32x2_t){b[0], b[1]} + b01) * cs2;
-            c23 = gemm_act2<ACT, SCALAR_ACT>((f32x2_t){b[2], b[3]} + b23) * cs2;
+            a01 = gemm_act2<ACT, SCALAR_ACT>(va01) * cs2;
+            a23 = gemm_act2<ACT, SCALAR_ACT>(va23) * cs2;
+            c01 = gemm_act2<ACT, SCALAR_ACT>(vb01) * cs2;
+            c23 = gemm_act2<ACT, SCALAR_ACT>(vb23) * cs2;
           }
           if constexpr (RES) {
             const X4 ra = __builtin_bit_cast(X4, resA[nt]), rb = __builtin_bit_cast(X4, resB[nt]);

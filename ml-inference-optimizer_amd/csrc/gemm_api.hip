@@ -293,7 +293,8 @@ extern "C" int mio_fused_mlp_glu_fwd_bw(const void* x, const void* wgu_b, const 
 // layernorm_kernels.py:35-188 (residual add + LayerNorm in one pass).  Here neither a prologue nor a pass: the GEMM that
 // WRITES the residual stream (out-proj / fc2, residual epilogue) also writes each output row's (sum, sum of squares) per
 // 256-column tile, and the projection BEHIND the LayerNorm multiplies the raw stream with gamma-scaled weights and applies
-// mean / rstd in its read-out:  LN(x) W^T + b = rstd * (x W'^T - mean * c) + b',  W' = gamma o W, c = W' 1, b' = b + W beta.
+// rstd in its read-out:  LN(x) W^T + b = rstd * (x - mean 1) (gamma o W)^T + b' = rstd * x W'^T + b',  W' = gamma o W with every
+// row's mean over k subtracted (the centring moves from the activations to the weights), b' = b + W beta.
 extern "C" size_t mio_ln_stats_bytes(int64_t M, int32_t width) {
   return (size_t)((width + 255) / 256) * (size_t)((M + 255) / 256 * 256) * 2 * sizeof(float);
 }
@@ -306,21 +307,18 @@ extern "C" int32_t mio_gemm_ln_ok(int64_t M, int32_t N, int32_t K, int32_t act, 
   return 1;
 }
 
-// one workgroup per weight row: w_scaled[n][k] = T(w[n][k] * gamma[k]), cvec[n] = sum_k w_scaled[n][k] (of the ROUNDED
-// products: what the matrix core multiplies), bias_out[n] = T(bias[n] + sum_k w[n][k] * beta[k])
+// one workgroup per weight row: w_scaled[n][k] = T(w[n][k] * gamma[k] - mean_k(w[n][.] * gamma[.])) (the row mean is taken over
+// the unrounded products), bias_out[n] = T(bias[n] + sum_k w[n][k] * beta[k])
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fold_weight_kernel(const T* __restrict__ w, int64_t ldw, const T* __restrict__ gamma,
                                                              const T* __restrict__ beta, const T* __restrict__ bias,
-                                                             T* __restrict__ ws, float* __restrict__ cvec, T* __restrict__ bias_out,
-                                                             int K) {
+                                                             T* __restrict__ ws, T* __restrict__ bias_out, int K) {
   __shared__ float s_c[256], s_b[256];
   const int n = blockIdx.x, t = threadIdx.x;
   float c = 0.f, bb = 0.f;
   for (int k = t; k < K; k += 256) {
     const float wv = (float)w[(int64_t)n * ldw + k];
-    const T r = (T)(wv * (float)gamma[k]);
-    ws[(int64_t)n * K + k] = r;
-    c += (float)r;
+    c += wv * (float)gamma[k];
     if (beta != nullptr) bb += wv * (float)beta[k];
   }
   s_c[t] = c;
@@ -333,24 +331,22 @@ __global__ __launch_bounds__(256) void ln_fold_weight_kernel(const T* __restrict
     }
     __syncthreads();
   }
-  if (t == 0) {
-    cvec[n] = s_c[0];
-    bias_out[n] = (T)((bias != nullptr ? (float)bias[n] : 0.f) + s_b[0]);
-  }
+  const float mean = s_c[0] / (float)K;
+  for (int k = t; k < K; k += 256) ws[(int64_t)n * K + k] = (T)((float)w[(int64_t)n * ldw + k] * (float)gamma[k] - mean);
+  if (t == 0) bias_out[n] = (T)((bias != nullptr ? (float)bias[n] : 0.f) + s_b[0]);
 }
 
 extern "C" int mio_ln_fold_weight(const void* w, int64_t ldw, const void* gamma, const void* beta, const void* bias,
-                                  void* w_scaled, float* cvec, void* bias_out, int32_t N, int32_t K, int32_t dtype, void* stream) {
-  MIO_CHECK(w && gamma && w_scaled && cvec && bias_out, "mio_ln_fold_weight: w, gamma, w_scaled, cvec, bias_out must be non-null");
+                                  void* w_scaled, void* bias_out, int32_t N, int32_t K, int32_t dtype, void* stream) {
+  MIO_CHECK(w && gamma && w_scaled && bias_out, "mio_ln_fold_weight: w, gamma, w_scaled, bias_out must be non-null");
   MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_ln_fold_weight: dtype must be bf16 or fp16");
   MIO_CHECK(N > 0 && K > 0 && ldw >= K, "mio_ln_fold_weight: bad sizes");
   if (dtype == MIO_BF16)
     hipLaunchKernelGGL(ln_fold_weight_kernel<__bf16>, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, (const __bf16*)w, ldw,
-                       (const __bf16*)gamma, (const __bf16*)beta, (const __bf16*)bias, (__bf16*)w_scaled, cvec, (__bf16*)bias_out, K);
+                       (const __bf16*)gamma, (const __bf16*)beta, (const __bf16*)bias, (__bf16*)w_scaled, (__bf16*)bias_out, K);
   else
     hipLaunchKernelGGL(ln_fold_weight_kernel<_Float16>, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)w, ldw,
-                       (const _Float16*)gamma, (const _Float16*)beta, (const _Float16*)bias, (_Float16*)w_scaled, cvec,
-                       (_Float16*)bias_out, K);
+                       (const _Float16*)gamma, (const _Float16*)beta, (const _Float16*)bias, (_Float16*)w_scaled, (_Float16*)bias_out, K);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mio_fail(std::string("mio_ln_fold_weight launch: ") + hipGetErrorString(e));
   return 0;
@@ -358,15 +354,14 @@ extern "C" int mio_ln_fold_weight(const void* w, int64_t ldw, const void* gamma,
 
 extern "C" int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, const void* residual, void* y, int64_t M, int32_t N,
                               int32_t K, int64_t ldx, int64_t ldy, int64_t ldr, int32_t act, int32_t dtype, int32_t flags,
-                              const float* ln_stats, const float* ln_cvec, float ln_eps, float* stats_out, int32_t cs_lo,
-                              int32_t cs_hi, float cs_val, void* stream) {
+                              const float* ln_stats, float ln_eps, float* stats_out, int32_t cs_lo, int32_t cs_hi, float cs_val,
+                              void* stream) {
   const bool xb = (flags & MIO_GEMM_X_BLOCKED) != 0, yb = (flags & MIO_GEMM_Y_BLOCKED) != 0, rb = (flags & MIO_GEMM_RES_BLOCKED) != 0;
   MIO_CHECK(x && wb && y, "mio_gemm_ln_bw: x, wb, y must be non-null");
   MIO_CHECK(M > 0 && N > 0 && K > 0, "mio_gemm_ln_bw: bad sizes");
   MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_gemm_ln_bw: dtype must be bf16 or fp16");
   MIO_CHECK(act >= MIO_ACT_NONE && act < MIO_ACT_SWIGLU, "mio_gemm_ln_bw: unknown / unsupported activation");
   MIO_CHECK((flags & ~7) == 0, "mio_gemm_ln_bw: unknown flag");
-  MIO_CHECK((ln_stats == nullptr) == (ln_cvec == nullptr), "mio_gemm_ln_bw: ln_stats and ln_cvec come together");
   MIO_CHECK(mio_gemm_ln_ok(M, N, K, act, ln_stats != nullptr, stats_out != nullptr),
             "mio_gemm_ln_bw: this shape / activation does not take the folded kernels (mio_gemm_ln_ok == 0)");
   MIO_CHECK(ln_stats == nullptr || residual == nullptr, "mio_gemm_ln_bw: the consumer form takes no residual");
@@ -381,7 +376,7 @@ extern "C" int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, c
   MIO_CHECK(ldx * 512 < (int64_t)0x7fffffff && ldy * 512 < (int64_t)0x7fffffff && (residual == nullptr || ldr * 512 < (int64_t)0x7fffffff),
             "mio_gemm_ln_bw: row stride too large");
   MIO_CHECK(mio_aligned16(x) && mio_aligned16(wb) && mio_aligned16(y) && mio_aligned16(residual) && mio_aligned16(bias) &&
-                mio_aligned16(ln_stats) && mio_aligned16(ln_cvec) && mio_aligned16(stats_out),
+                mio_aligned16(ln_stats) && mio_aligned16(stats_out),
             "mio_gemm_ln_bw: pointers must be 16-byte aligned");
   MIO_CHECK(cs_lo >= cs_hi || (residual == nullptr && cs_lo >= 0 && cs_hi <= N && cs_lo % 128 == 0 && cs_hi % 128 == 0),
             "mio_gemm_ln_bw: [cs_lo, cs_hi) must be multiples of 128 inside [0, N], without a residual");
@@ -391,7 +386,7 @@ extern "C" int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, c
   p.M = M; p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.ldr = ldr; p.N = N; p.K = K;
   p.x_blk = xb ? 1 : 0; p.y_blk = yb ? 1 : 0; p.w_blk = 1; p.res_blk = rb ? 1 : 0;
   p.cs_lo = cs_lo; p.cs_hi = cs_hi; p.cs_val = cs_val;
-  p.ln_stats = ln_stats; p.ln_cvec = ln_cvec; p.ln_eps = ln_eps; p.ln_slots = ln_stats ? K / 256 : 0;
+  p.ln_stats = ln_stats; p.ln_eps = ln_eps; p.ln_slots = ln_stats ? K / 256 : 0;
   p.stats_out = stats_out;
   return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
 }

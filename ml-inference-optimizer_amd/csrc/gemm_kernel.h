@@ -48,11 +48,11 @@ struct GemmDev {
   // kernels/triton/fused_layernorm_qkv.py:37-420, layernorm_kernels.py:35-188):
   //   producer (the GEMM that writes the residual stream, FOLD = 2): stats_out[slot][row] = (sum, sum of squares) of the ROUNDED
   //     output row over the tile column `slot` (N / 256 slots, rows padded to whole 256-row tiles);
-  //   consumer (the projection behind the LayerNorm, FOLD = 1): w holds gamma-scaled weights, bias the beta-folded bias,
-  //     ln_cvec[n] = sum_k w'[n][k]; the read-out computes (acc - mean * cvec) * rstd + bias from ln_stats (ln_slots slots).
+  //   consumer (the projection behind the LayerNorm, FOLD = 1): w holds the gamma-scaled weights with every row's mean over k
+  //     subtracted ((x - mean 1) . w = x . (w - mean(w) 1): the centring moves from the activations to the weights), bias the
+  //     beta-folded bias; the read-out computes acc * rstd + bias, rstd from ln_stats (ln_slots slots).
   int res_blk;             // the residual is in the blocked activation layout (width N)
   const float* ln_stats;   // consumer: [ln_slots][tiles_m * 256][2]
-  const float* ln_cvec;    // consumer: [N]
   float* stats_out;        // producer: [N / 256][tiles_m * 256][2]
   int ln_slots;
   float ln_eps;
@@ -64,7 +64,7 @@ static inline void gemm_dev_defaults(GemmDev& p) {
   p.x_blk = p.y_blk = p.w_blk = 0;
   p.dbg = nullptr;
   p.cs_lo = p.cs_hi = 0; p.cs_val = 1.f; p.group_m = 0;
-  p.res_blk = 0; p.ln_stats = nullptr; p.ln_cvec = nullptr; p.stats_out = nullptr; p.ln_slots = 0; p.ln_eps = 0.f;
+  p.res_blk = 0; p.ln_stats = nullptr; p.stats_out = nullptr; p.ln_slots = 0; p.ln_eps = 0.f;
 }
 
 int mio_gemm_impl();  // MIO_GEMM_IMPL override (0 = default dispatch); defined in gemm_api.hip

@@ -77,6 +77,48 @@ def _get_blocked_glu(self, gate: torch.Tensor, up: torch.Tensor, dtype: torch.dt
 CastCache.get_blocked_glu = _get_blocked_glu
 
 
+def _get_ln_folded(self, lin: nn.Linear, ln: nn.LayerNorm, dtype: torch.dtype):
+    """(blocked gamma-scaled, row-centred weight, beta-folded bias) of a projection behind LayerNorm `ln` (ops.ln_fold_weight),
+    prepared once per version of the four parameters involved."""
+    ps = (lin.weight, lin.bias, ln.weight, ln.bias)
+    key = tuple((None if t is None else (t.data_ptr(), t._version)) for t in ps) + (dtype, lin.weight.device, "ln_fold")
+    slot = ("f", id(lin.weight), id(ln.weight))
+    hit = self._c.get(slot)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    t = ops.ln_fold_weight(self.get(lin.weight, dtype), self.get(ln.weight, dtype), self.get(ln.bias, dtype), self.get(lin.bias, dtype))
+    self._c[slot] = (key, t)
+    return t
+
+
+CastCache.get_ln_folded = _get_ln_folded
+
+
+class ResidualStream:
+    """The residual stream between two sub-layers as the folded kernels hand it on (ops.gemm_ln): `blocked` is the
+    [ceil(M/256)*256, d] tensor in the blocked activation layout, `stats` the (sum, sum of squares) row statistics its
+    producer wrote beside it ([d/256, ceil(M/256)*256, 2] fp32), `shape` the logical (B, S, d).  A sub-layer that takes a
+    ResidualStream normalises inside its first GEMM's read-out and reads the residual from `blocked`; no LayerNorm launch."""
+    __slots__ = ("blocked", "stats", "shape")
+
+    def __init__(self, blocked: torch.Tensor, stats: torch.Tensor, shape: Tuple[int, int, int]):
+        self.blocked, self.stats, self.shape = blocked, stats, tuple(shape)
+
+    @property
+    def dtype(self):
+        return self.blocked.dtype
+
+    @property
+    def device(self):
+        return self.blocked.device
+
+    def dense(self) -> torch.Tensor:
+        """Row-major [B, S, d] copy (tests / debugging: a strided view copied by torch, not a kernel of this package)."""
+        B, S, d = self.shape
+        mp = self.blocked.shape[0]
+        return self.blocked.view(mp // 256, d // 32, 256, 32).permute(0, 2, 1, 3).reshape(mp, d)[:B * S].reshape(B, S, d)
+
+
 def linear(x: torch.Tensor, lin: nn.Linear, cache: CastCache, dtype: torch.dtype, activation: str = "none",
            residual: Optional[torch.Tensor] = None, col_scale=None, x_blocked_shape=None) -> torch.Tensor:
     """F.linear(x, W, b) (+ activation, + residual) on the MFMA GEMM.  At sizes that run the 256x256-tile kernels the

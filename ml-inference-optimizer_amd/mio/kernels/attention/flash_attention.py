@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ..._nn import CastCache, compute_dtype, linear, prenorm_linear
+from ..._nn import CastCache, ResidualStream, compute_dtype, linear, prenorm_linear
 
 
 @dataclass
@@ -204,11 +204,70 @@ class FlashSelfAttention(_AttentionBase):
             nn.init.normal_(lin.weight, mean=0.0, std=0.02)
             nn.init.zeros_(lin.bias)
 
+    def stream_ok(self, B: int, S: int, dtype: torch.dtype, pre_norm: Optional[nn.LayerNorm]) -> bool:
+        """True iff forward(...) can take / return the residual stream as a ResidualStream at this size: the pre-scaled-K
+        attention with its blocked output, and the folded GEMMs on both projections (ops.gemm_ln_ok)."""
+        cfg = self.config
+        d, q_dim, kv_dim = self.qkv_proj.in_features, self.hidden_size, self.num_kv_heads * self.head_dim
+        n_tot, M = q_dim + 2 * kv_dim, B * S
+        if dtype not in (torch.float16, torch.bfloat16) or pre_norm is None or pre_norm.weight is None or ops.NO_BLOCKED_X:
+            return False
+        if compute_dtype(cfg.precision, torch.empty(0, dtype=dtype)) != dtype:
+            return False  # the stream form runs in the stream's dtype
+        if tuple(pre_norm.normalized_shape) != (d,) or self.o_proj.out_features != d or q_dim != d:
+            return False
+        if cfg.normalize_query or cfg.return_softmax or (self.training and cfg.dropout_p > 0.0):
+            return False
+        return (q_dim % 128 == 0 and kv_dim % 128 == 0
+                and ops.fa3_k_prescaled_ok(B, S, S, self.num_attention_heads, self.head_dim, n_tot, n_tot)
+                and ops.fa3_o_blocked_ok(B, S, S, self.num_attention_heads, self.head_dim, n_tot, n_tot)
+                and ops.col_scale_ok(M, n_tot, d) and ops.blocked_weight_ok(M, n_tot, d)
+                and ops.gemm_ln_ok(M, n_tot, d, "none", fold_in=True) and ops.gemm_ln_ok(M, d, q_dim, "none", stats_out=True))
+
+    def _forward_stream(self, x, pre_norm: nn.LayerNorm, stream_out: bool):
+        """The folded form: x is a ResidualStream (QKV normalises in its read-out, the output projection reads the residual from
+        the blocked stream) or a [B, S, d] tensor (LayerNorm kernel in front, as forward() does); the output projection writes
+        the new stream blocked + its row statistics (stream_out) or a plain [B, S, d] tensor."""
+        c, cfg = self._cast, self.config
+        is_stream = isinstance(x, ResidualStream)
+        B, S, d = x.shape
+        dt = x.dtype
+        M = B * S
+        q_dim, kv_dim = self.hidden_size, self.num_kv_heads * self.head_dim
+        n_tot = q_dim + 2 * kv_dim
+        sc = cfg.softmax_scale if cfg.softmax_scale is not None else 1.0 / math.sqrt(self.head_dim)
+        cs = (q_dim, q_dim + kv_dim, sc * 1.4426950408889634)
+        if is_stream:
+            wfb, bfold = c.get_ln_folded(self.qkv_proj, pre_norm, dt)
+            qkv, _ = ops.gemm_ln(x.blocked, wfb, bfold, M=M, N=n_tot, K=d, x_blocked=True, ln_stats=x.stats, eps=pre_norm.eps,
+                                 col_scale=cs)
+            qkv = qkv.view(B, S, n_tot)
+            res, res_blocked = x.blocked, True
+        else:
+            qkv = prenorm_linear(x, pre_norm, self.qkv_proj, c, dt, col_scale=cs)
+            res, res_blocked = x.reshape(M, d), False
+        q = qkv[:, :, :q_dim].view(B, S, self.num_attention_heads, self.head_dim)
+        k = qkv[:, :, q_dim:q_dim + kv_dim].view(B, S, self.num_kv_heads, self.head_dim)
+        v = qkv[:, :, q_dim + kv_dim:].view(B, S, self.num_kv_heads, self.head_dim)
+        ctx_b = ops.fa3_fwd(q, k, v, causal=cfg.causal, k_prescaled=True, out_blocked=True)
+        y, st = ops.gemm_ln(ctx_b, c.get_blocked(self.o_proj.weight, dt), c.get(self.o_proj.bias, dt), M=M, N=d, K=q_dim,
+                            x_blocked=True, residual=res, res_blocked=res_blocked, out_blocked=stream_out, stats_out=stream_out)
+        return ResidualStream(y, st, (B, S, d)) if stream_out else y.view(B, S, d)
+
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, pre_norm: Optional[nn.LayerNorm] = None,
-                **kwargs: Any) -> torch.Tensor:
+                stream_out: bool = False, **kwargs: Any) -> torch.Tensor:
         """pre_norm (not in the reference): a LayerNorm to apply to hidden_states first -- the pre-LN block's
-        `attn(ln(x))` in one call, which lets LayerNorm hand its output to the QKV GEMM in the blocked layout."""
+        `attn(ln(x))` in one call, which lets LayerNorm hand its output to the QKV GEMM in the blocked layout.
+        hidden_states may be a ResidualStream (mio._nn) and stream_out=True returns one, where stream_ok() says so: the
+        residual is then the stream itself (`x + attn(ln(x))`) and the LayerNorm is folded into the GEMMs (ops.gemm_ln)."""
+        if isinstance(hidden_states, ResidualStream) or stream_out:
+            B, S, _ = hidden_states.shape
+            if attention_mask is not None or kwargs or (residual is not None and residual is not hidden_states) or \
+                    not self.stream_ok(B, S, hidden_states.dtype, pre_norm):
+                raise ValueError("the ResidualStream form needs pre_norm, residual = the input itself, no mask / paged arguments "
+                                 "and a size with stream_ok()")
+            return self._forward_stream(hidden_states, pre_norm, stream_out)
         if hidden_states.dim() != 3:
             raise ValueError(f"Expected 3D input tensor, got shape: {hidden_states.shape}")
         if not hidden_states.is_cuda:

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ..._nn import CastCache, compute_dtype
+from ..._nn import CastCache, ResidualStream, compute_dtype
 
 
 @dataclass
@@ -58,10 +58,48 @@ class FusedMLP(nn.Module):
     def _gate(self, dtype):
         return None, None
 
+    def stream_ok(self, B: int, S: int, dtype: torch.dtype, pre_norm: Optional[nn.LayerNorm]) -> bool:
+        """True iff forward(...) can take (and return) the residual stream as a ResidualStream at this size (ops.gemm_ln_ok on
+        both GEMMs; GELU-tanh or no activation -- the gated stage has no folded form)."""
+        act = self._kernel_activation()
+        d, I, M = self.fc1.in_features, self.fc1.out_features, B * S
+        if dtype not in (torch.float16, torch.bfloat16) or pre_norm is None or pre_norm.weight is None or ops.NO_BLOCKED_X:
+            return False
+        if compute_dtype(self.config.precision, torch.empty(0, dtype=dtype)) != dtype:
+            return False  # the stream form runs in the stream's dtype
+        if act != "gelu" or tuple(pre_norm.normalized_shape) != (d,) or self.fc2.out_features != d:
+            return False
+        if self.training and self.dropout is not None:
+            return False
+        return (ops.fused_mlp_blocked_weight_ok(M, d, I, act) and ops.gemm_ln_ok(M, I, d, act, fold_in=True)
+                and ops.gemm_ln_ok(M, d, I, "none", stats_out=True))
+
+    def _forward_stream(self, x: ResidualStream, pre_norm: nn.LayerNorm, stream_out: bool):
+        """fc1 normalises the raw stream in its read-out and writes act(...) blocked; fc2 reads the residual from the blocked
+        stream and writes the new stream (blocked + row statistics) or a plain [B, S, d] tensor."""
+        c, act = self._cast, self._kernel_activation()
+        B, S, d = x.shape
+        dt, M, I = x.dtype, B * S, self.fc1.out_features
+        wfb, bfold = c.get_ln_folded(self.fc1, pre_norm, dt)
+        h, _ = ops.gemm_ln(x.blocked, wfb, bfold, M=M, N=I, K=d, activation=act, x_blocked=True, out_blocked=True,
+                           ln_stats=x.stats, eps=pre_norm.eps)
+        y, st = ops.gemm_ln(h, c.get_blocked(self.fc2.weight, dt), c.get(self.fc2.bias, dt), M=M, N=d, K=I, x_blocked=True,
+                            residual=x.blocked, res_blocked=True, out_blocked=stream_out, stats_out=stream_out)
+        return ResidualStream(y, st, (B, S, d)) if stream_out else y.view(B, S, d)
+
     def forward(self, hidden_states: torch.Tensor, residual: Optional[torch.Tensor] = None,
-                pre_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
+                pre_norm: Optional[nn.LayerNorm] = None, stream_out: bool = False) -> torch.Tensor:
         """pre_norm (not in the reference): a LayerNorm to apply to hidden_states first -- the pre-LN block's
-        `mlp(ln(x))` in one call, which lets LayerNorm hand its output to fc1 in the blocked layout."""
+        `mlp(ln(x))` in one call, which lets LayerNorm hand its output to fc1 in the blocked layout.
+        hidden_states may be a ResidualStream (mio._nn; the residual is then the stream itself and the LayerNorm is folded into
+        fc1's read-out, ops.gemm_ln); stream_out=True returns one.  Where stream_ok() says so."""
+        if isinstance(hidden_states, ResidualStream):
+            B, S, _ = hidden_states.shape
+            if (residual is not None and residual is not hidden_states) or not self.stream_ok(B, S, hidden_states.dtype, pre_norm):
+                raise ValueError("the ResidualStream form needs pre_norm, residual = the input itself and a size with stream_ok()")
+            return self._forward_stream(hidden_states, pre_norm, stream_out)
+        if stream_out:
+            raise ValueError("stream_out needs a ResidualStream input (the attention sub-layer produces the first one)")
         if hidden_states.dim() != 3:
             raise ValueError(f"Expected 3D input tensor, got shape: {hidden_states.shape}")
         if not hidden_states.is_cuda:
@@ -149,8 +187,13 @@ class FusedTransformerMLP(nn.Module):
         else:
             self.mlp = FusedMLP(hidden_size, intermediate_size, self.config)
 
+    def stream_ok(self, B: int, S: int, dtype: torch.dtype, pre_norm: Optional[nn.LayerNorm]) -> bool:
+        return self.mlp.stream_ok(B, S, dtype, pre_norm)
+
     def forward(self, hidden_states: torch.Tensor, residual: Optional[torch.Tensor] = None,
-                pre_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
+                pre_norm: Optional[nn.LayerNorm] = None, stream_out: bool = False) -> torch.Tensor:
+        if isinstance(hidden_states, ResidualStream) or stream_out:
+            return self.mlp(hidden_states, residual, pre_norm, stream_out)
         if pre_norm is not None:
             return self.mlp(hidden_states, residual, pre_norm)
         return self.mlp(hidden_states, residual) if residual is not None else self.mlp(hidden_states)

@@ -451,14 +451,15 @@ def gemm_bias_act(x, w, bias=None, activation: str = "none", w_gate=None, bias_g
 
 # ---- LayerNorm folded into the GEMMs on either side of it (mio_gemm_ln_bw; reference fused_layernorm_qkv.py:37-420) ------------
 def gemm_ln_ok(M: int, N: int, K: int, activation: str = "none", fold_in: bool = False, stats_out: bool = False) -> bool:
-    """True iff gemm_ln(...) runs this shape: fold_in = the projection behind a LayerNorm (ln_stats / ln_cvec given),
+    """True iff gemm_ln(...) runs this shape: fold_in = the projection behind a LayerNorm (ln_stats given),
     stats_out = the residual GEMM that also writes the row statistics of its output."""
     return not _NO_BLOCKED_W and bool(lib.mio_gemm_ln_ok(M, N, K, _ACT.get(activation, _lib.ACT_NONE), int(fold_in), int(stats_out)))
 
 
 def ln_fold_weight(w: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], bias: Optional[torch.Tensor]):
     """One-time preparation of a projection that sits behind a LayerNorm(gamma, beta): returns
-    (blocked gamma-scaled weight, cvec fp32 [N] = its row sums, bias' [N] = bias + w @ beta)."""
+    (blocked weight = gamma-scaled rows with their mean over k subtracted, bias' [N] = bias + w @ beta).  With the rows centred
+    x @ w'^T equals (x - mean(x)) @ (gamma * w)^T, so gemm_ln's read-out only multiplies by rstd and adds bias'."""
     _need_cuda(w, gamma)
     dt = _dtype_id(w)
     N, K = w.shape
@@ -467,11 +468,10 @@ def ln_fold_weight(w: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Te
     _vec_ok(bias, N, w.dtype, "bias")
     w = _rows16(w)
     ws = torch.empty(N, K, dtype=w.dtype, device=w.device)
-    cvec = torch.empty(N, dtype=torch.float32, device=w.device)
     bout = torch.empty(N, dtype=w.dtype, device=w.device)
     check(lib.mio_ln_fold_weight(w.data_ptr(), w.stride(0), gamma.data_ptr(), _ptr(beta), _ptr(bias), ws.data_ptr(),
-                                 cvec.data_ptr(), bout.data_ptr(), N, K, dt, _stream()))
-    return block_weight(ws), cvec, bout
+                                 bout.data_ptr(), N, K, dt, _stream()))
+    return block_weight(ws), bout
 
 
 def ln_stats_shape(M: int, width: int):
@@ -481,12 +481,12 @@ def ln_stats_shape(M: int, width: int):
 def gemm_ln(x: torch.Tensor, w_blocked: torch.Tensor, bias: Optional[torch.Tensor], *, M: int, N: int, K: int,
             activation: str = "none", x_blocked: bool = False, residual: Optional[torch.Tensor] = None,
             res_blocked: bool = False, out_blocked: bool = False, ln_stats: Optional[torch.Tensor] = None,
-            ln_cvec: Optional[torch.Tensor] = None, eps: float = 1e-5, stats_out: bool = False, col_scale=None):
+            eps: float = 1e-5, stats_out: bool = False, col_scale=None):
     """y = act(LN?(x) @ w^T + bias) (+ residual) on the 256-tile kernels with the LayerNorm folded in (module docstring of
     include/mio_hip.h, "LayerNorm folded into the GEMMs on either side of it").  Operands are [M, *] row-major 2-D tensors or,
     where the *_blocked flag says so, [ceil(M/256)*256, *] tensors in the blocked activation layout.
-      ln_stats + ln_cvec: x is the raw residual stream, w_blocked / bias / ln_cvec come from ln_fold_weight(...), ln_stats from
-                          the GEMM that wrote x (stats_out=True);
+      ln_stats:           x is the raw residual stream, w_blocked / bias come from ln_fold_weight(...), ln_stats from the GEMM
+                          that wrote x (stats_out=True);
       stats_out=True:     also returns the (sum, sum of squares) statistics of the rounded output rows.
     Returns (y, stats) -- stats is None unless stats_out."""
     _need_cuda(x, w_blocked)
@@ -494,8 +494,6 @@ def gemm_ln(x: torch.Tensor, w_blocked: torch.Tensor, bias: Optional[torch.Tenso
         raise ValueError(f"Unsupported activation function: {activation}")
     act, dt = _ACT[activation], _dtype_id(x)
     fold = ln_stats is not None
-    if (ln_cvec is None) == fold:
-        raise ValueError("ln_stats and ln_cvec come together")
     if not lib.mio_gemm_ln_ok(M, N, K, act, int(fold), int(stats_out)):
         raise ValueError("gemm_ln: this shape / activation does not take the folded kernels (gemm_ln_ok)")
     mp = (M + 255) // 256 * 256
@@ -522,8 +520,6 @@ def gemm_ln(x: torch.Tensor, w_blocked: torch.Tensor, bias: Optional[torch.Tenso
         want = ln_stats_shape(M, K)
         if ln_stats.dtype != torch.float32 or tuple(ln_stats.shape) != want or not ln_stats.is_contiguous() or ln_stats.device != x.device:
             raise ValueError(f"ln_stats: expected a contiguous fp32 tensor of shape {want}")
-        if ln_cvec.dtype != torch.float32 or ln_cvec.numel() != N or not ln_cvec.is_contiguous() or ln_cvec.device != x.device:
-            raise ValueError(f"ln_cvec: expected {N} contiguous fp32 elements")
     lo = hi = 0
     val = 1.0
     if col_scale is not None:
@@ -534,7 +530,7 @@ def gemm_ln(x: torch.Tensor, w_blocked: torch.Tensor, bias: Optional[torch.Tenso
     st = torch.empty(ln_stats_shape(M, N), dtype=torch.float32, device=x.device) if stats_out else None
     flags = (1 if x_blocked else 0) | (2 if out_blocked else 0) | (4 if (res_blocked and residual is not None) else 0)
     check(lib.mio_gemm_ln_bw(x2.data_ptr(), w_blocked.data_ptr(), _ptr(bias), _ptr(r2), y.data_ptr(), M, N, K, ldx, N, ldr,
-                             act, dt, flags, _ptr(ln_stats), _ptr(ln_cvec), float(eps), _ptr(st), lo, hi, val, _stream()))
+                             act, dt, flags, _ptr(ln_stats), float(eps), _ptr(st), lo, hi, val, _stream()))
     return y, st
 
 

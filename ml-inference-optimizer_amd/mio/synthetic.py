@@ -14,6 +14,7 @@ from . import ops
 from .kernels.attention.flash_attention import FlashAttentionConfig, FlashSelfAttention
 from .kernels.attention.ring_attention import RingAttentionConfig, RingCrossAttention
 from .kernels.mlp.fused_mlp import FusedMLPConfig, FusedTransformerMLP
+from ._nn import ResidualStream
 
 
 class FusedLayerNorm(nn.LayerNorm):
@@ -36,7 +37,20 @@ class Block(nn.Module):
         self.ln_2 = FusedLayerNorm(d)
         self.mlp = FusedTransformerMLP(d, I, activation, FusedMLPConfig(precision=precision))
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def stream_ok(self, B: int, S: int, dtype: torch.dtype) -> bool:
+        """The block can run with both LayerNorms folded into the GEMMs around them (mio._nn.ResidualStream)."""
+        return self.attn.stream_ok(B, S, dtype, self.ln_1) and self.mlp.stream_ok(B, S, dtype, self.ln_2)
+
+    def forward(self, x, stream_out: bool = False, fold: bool = True):
+        """x: [B, S, d] tensor or the ResidualStream of the previous block (fold=False: every LayerNorm as its own kernel).  Where stream_ok(): ln_2 is folded into the output
+        projection (statistics) and fc1 (normalisation), and with stream_out the next block's ln_1 into fc2 and its QKV GEMM --
+        the residual stream then never leaves the blocked layout and no LayerNorm kernel runs between the GEMMs."""
+        B, S, _ = x.shape
+        if isinstance(x, ResidualStream) or (fold and self.stream_ok(B, S, x.dtype)):
+            a = self.attn(x, residual=x, pre_norm=self.ln_1, stream_out=True)
+            return self.mlp(a, residual=a, pre_norm=self.ln_2, stream_out=stream_out)
+        if stream_out:
+            raise ValueError("stream_out needs a size / dtype with stream_ok()")
         # pre_norm=: the module applies the LayerNorm itself (same kernels; at large sizes LayerNorm then writes its
         # output in the blocked layout the following GEMM fetches contiguously)
         x = self.attn(x, residual=x, pre_norm=self.ln_1)
@@ -93,6 +107,7 @@ class GPT2ShapedStack(nn.Module):
         self.h = nn.ModuleList([Block(hidden_size, num_heads, I, causal, precision, activation)
                                 for _ in range(num_layers)])
         self.ln_f = FusedLayerNorm(hidden_size)
+        self.no_ln_fold = False  # True: every LayerNorm runs as its own kernel (A/B of the fold, tools/ln_fold_ab.py)
         g = torch.Generator().manual_seed(seed)
         with torch.no_grad():  # N(0, 0.02) weights, zero biases (flash_attention.py:534-542)
             for m in self.modules():
@@ -102,6 +117,9 @@ class GPT2ShapedStack(nn.Module):
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        for blk in self.h:
-            x = blk(x)
+        B, S, _ = x.shape
+        fold = not self.no_ln_fold and all(blk.stream_ok(B, S, x.dtype) for blk in self.h)
+        last = len(self.h) - 1
+        for i, blk in enumerate(self.h):
+            x = blk(x, stream_out=(fold and i < last), fold=fold)  # the last block hands a plain tensor to ln_f
         return self.ln_f(x)

@@ -54,15 +54,17 @@ def _rel(a, b):
     return (d.mean() / b.abs().mean().clamp_min(1e-12)).item(), d.max().item()
 
 
-def _record(name, got, truth, ref16, extra=None):
-    """got: kernel output (16-bit); truth: fp32 chain; ref16: the reference's chain evaluated in the storage dtype."""
+def _record(name, got, truth, ref16, extra=None, bar=None):
+    """got: kernel output (16-bit); truth: fp32 chain; ref16: the reference's chain evaluated in the storage dtype.
+    bar: the absolute bound on the kernel's relative error (BF16_REL for one op / one block)."""
+    bar = BF16_REL if bar is None else bar
     k_rel, k_max = _rel(got, truth)
     r_rel, r_max = _rel(ref16, truth)
     q_rel, q_max = _rel(truth.to(got.dtype), truth)  # pure output rounding: the floor for any 16-bit result
     PARITY[name] = dict(kernel_rel_err=k_rel, kernel_max_abs=k_max, reference_bf16_rel_err=r_rel,
                         reference_bf16_max_abs=r_max, rounding_floor_rel_err=q_rel, dtype=str(got.dtype), **(extra or {}))
     assert k_rel <= 1.25 * r_rel, f"{name}: kernel rel_err {k_rel:.3e} > 1.25 x reference bf16 chain {r_rel:.3e}"
-    assert k_rel < BF16_REL, f"{name}: kernel rel_err {k_rel:.3e}"
+    assert k_rel < bar, f"{name}: kernel rel_err {k_rel:.3e}"
     return k_rel, r_rel
 
 
@@ -517,6 +519,66 @@ def test_c2_block_b8_s4096():
     want = oracle.fused_mlp(h2, blk.mlp.mlp.fc1.weight.cpu(), blk.mlp.mlp.fc1.bias.cpu(), blk.mlp.mlp.fc2.weight.cpu(),
                             blk.mlp.mlp.fc2.bias.cpu(), "gelu", residual=a)
     _oracle_rows(name, y[b0][rows], want, torch.bfloat16)
+
+
+def test_c2_two_blocks_layernorm_folded():
+    """Two pre-LN blocks at B 8, S 4096 with EVERY LayerNorm between GEMMs folded into them (ResidualStream: block 1 hands
+    block 2 the blocked stream + row statistics, so block 2's ln_1 runs inside fc2 / QKV and both ln_2 inside out-proj / fc1)
+    against the unrounded fp32 chain and the reference's bf16 chain, and against the same blocks with separate LayerNorm kernels."""
+    from mio.synthetic import Block
+    from mio._nn import ResidualStream
+    B, S, d, H, I = C2["B"], C2["S"], C2["d"], C2["H"], C2["I"]
+    D = d // H
+    torch.manual_seed(1)
+    blks = [Block(d, H, I, causal=True, precision="bf16") for _ in range(2)]
+    with torch.no_grad():
+        for blk in blks:
+            for m in blk.modules():
+                if isinstance(m, torch.nn.Linear):
+                    m.weight.copy_(torch.randn(m.weight.shape) * 0.02)
+                    m.bias.copy_(torch.randn(m.bias.shape) * 0.02)
+                if isinstance(m, torch.nn.LayerNorm):
+                    m.weight.copy_(1 + 0.1 * torch.randn(m.weight.shape))
+                    m.bias.copy_(0.1 * torch.randn(m.bias.shape))
+    blks = [b.to(device=DEV, dtype=torch.bfloat16).eval() for b in blks]
+    (x,) = _c2_inputs(17, (B, S, d))
+    x = x + 0.25   # a residual stream with a mean: the fold subtracts mean * rstd * (row sums of the scaled weight)
+    assert blks[0].stream_ok(B, S, torch.bfloat16)
+    with torch.no_grad():
+        s1 = blks[0](x, stream_out=True)
+        assert isinstance(s1, ResidualStream)
+        y = blks[1](s1)
+        y_sep = blks[1](blks[0](x, fold=False), fold=False)
+        # the stream after block 1 is the same tensor either way up to the bf16 rounding of LN(x) vs of gamma * W
+        mid_sep = blks[0](x, fold=False)
+    mid = s1.dense()
+    rel_mid = ((mid.float() - mid_sep.float()).abs().mean() / mid_sep.float().abs().mean()).item()
+    rel_out = ((y.float() - y_sep.float()).abs().mean() / y_sep.float().abs().mean()).item()
+    assert rel_mid < 3e-3 and rel_out < 3e-3, (rel_mid, rel_out)
+
+    def chain(dt):
+        f = lambda t: t.to(dt)
+        h = f(x)
+        with torch.no_grad():
+            for blk in blks:
+                n1 = F.layer_norm(h, (d,), f(blk.ln_1.weight), f(blk.ln_1.bias), blk.ln_1.eps)
+                qkv = F.linear(n1, f(blk.attn.qkv_proj.weight), f(blk.attn.qkv_proj.bias))
+                q, k, v = (qkv[:, :, i * d:(i + 1) * d].reshape(B, S, H, D) for i in range(3))
+                ctx = (_attention_truth(q, k, v, True) if dt == torch.float32 else _attention_ref16(q, k, v, True)).to(dt)
+                a = F.linear(ctx.view(B, S, d), f(blk.attn.o_proj.weight), f(blk.attn.o_proj.bias)) + h
+                n2 = F.layer_norm(a, (d,), f(blk.ln_2.weight), f(blk.ln_2.bias), blk.ln_2.eps)
+                m = F.linear(F.gelu(F.linear(n2, f(blk.mlp.mlp.fc1.weight), f(blk.mlp.mlp.fc1.bias)), approximate="tanh"),
+                             f(blk.mlp.mlp.fc2.weight), f(blk.mlp.mlp.fc2.bias))
+                h = m + a
+        return h
+
+    truth = chain(torch.float32).view(-1, d)
+    sep_rel, _ = _rel(y_sep.view(-1, d), truth)
+    # two blocks deep the rounding of the first block's stream is amplified by the second: the bar is twice the one-block bar,
+    # the folded form may not be worse than the separate-kernel form by more than a tenth, nor than the reference's bf16 chain
+    k_rel, _ = _record("c2_two_blocks B8 S4096 d1024 H16 I4096, LayerNorms folded into the GEMMs", y.view(-1, d), truth,
+                       chain(torch.bfloat16).view(-1, d), extra={"separate_layernorm_kernels_rel_err": sep_rel}, bar=2 * BF16_REL)
+    assert k_rel <= 1.1 * sep_rel, (k_rel, sep_rel)
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -711,7 +711,7 @@ def test_gemm_ln_fold(dtype, act):
     M, d, N2 = 16500, 1024, 2048
     assert ops.gemm_ln_ok(M, d, d, "none", stats_out=True) and ops.gemm_ln_ok(M, N2, d, act, fold_in=True)
     x0 = torch.randn(M, d).to(dtype)
-    r0 = (torch.randn(M, d) * 2 + 0.3).to(dtype)   # a residual stream with a mean
+    r0 = (torch.randn(M, d) * 2 + 1.0).to(dtype)   # a residual stream whose row mean is half its deviation
     wp = (torch.randn(d, d) * 0.03).to(dtype)
     bp = (torch.randn(d) * 0.1).to(dtype)
     gamma, beta = (1 + 0.2 * torch.randn(d)).to(dtype), (0.1 * torch.randn(d)).to(dtype)
@@ -731,9 +731,9 @@ def test_gemm_ln_fold(dtype, act):
     yb2, st2 = ops.gemm_ln(x0d, wpb, bpd, M=M, N=d, K=d, residual=r0d, out_blocked=True, stats_out=True)
     assert torch.equal(st2[:, :M], st[:, :M]) and torch.equal(_unblock(yb2, M, d), y)   # deterministic (rows past M are never written)
     # -- consumer: z = act(LN(y) wc^T + bc) on the raw blocked stream
-    wfb, cvec, bfold = ops.ln_fold_weight(wcd, gd, btd, bcd)
+    wfb, bfold = ops.ln_fold_weight(wcd, gd, btd, bcd)
     zb, none = ops.gemm_ln(yb, wfb, bfold, M=M, N=N2, K=d, activation=act, x_blocked=True, out_blocked=True,
-                           ln_stats=st, ln_cvec=cvec, eps=1e-5)
+                           ln_stats=st, eps=1e-5)
     assert none is None
     z = _unblock(zb, M, N2)
     rows = torch.cat([torch.arange(0, M, 61), torch.tensor([255, 256, 16383, 16384, M - 1])])
@@ -744,10 +744,10 @@ def test_gemm_ln_fold(dtype, act):
         want = torch.nn.functional.gelu(want, approximate="tanh")
     _cmp(z[rows], want, dtype, f"ln-fold consumer {act}")
     # the same through row-major operands (x row-major, y row-major)
-    z2, _ = ops.gemm_ln(y, wfb, bfold, M=M, N=N2, K=d, activation=act, ln_stats=st, ln_cvec=cvec)
+    z2, _ = ops.gemm_ln(y, wfb, bfold, M=M, N=N2, K=d, activation=act, ln_stats=st)
     assert torch.equal(z2, z)
     # column scale on the folded read-out (the K columns of a QKV projection)
-    z3, _ = ops.gemm_ln(yb, wfb, bfold, M=M, N=N2, K=d, activation=act, x_blocked=True, ln_stats=st, ln_cvec=cvec,
+    z3, _ = ops.gemm_ln(yb, wfb, bfold, M=M, N=N2, K=d, activation=act, x_blocked=True, ln_stats=st,
                         col_scale=(1024, 2048, 0.25))
     assert torch.equal(z3[:, :1024], z[:, :1024])
     _cmp(z3[rows][:, 1024:], want[:, 1024:] * 0.25, dtype, "ln-fold consumer + col_scale")
