@@ -101,30 +101,73 @@ def _events_ms(fn, iters, warmup=3, sustain_ms=200.0):
 
 
 def kernel_rooflines(model, x, iters=10):
-    """Per-kernel time of ONE layer's launches on the layer's real weights and activations (layer 0 of the
-    benchmark stack, so the operand statistics -- and with them the clock the chip holds -- are the model's own),
+    """Per-kernel time of ONE layer's launches on the layer's real weights and activations (layer 1 of the benchmark stack,
+    reached through layer 0, so the operand statistics -- and with them the clock the chip holds -- are the model's own),
     HIP events on the launch stream -> which kernel dominates and its achieved fraction of the MFMA roofline
-    (algorithmic FLOPs: SURVEY.md 8d / BASELINE.md section 4)."""
+    (algorithmic FLOPs: SURVEY.md 8d / BASELINE.md section 4).  Where the blocks run with their LayerNorms folded into the
+    GEMMs (mio._nn.ResidualStream) the launches timed are those: QKV / fc1 normalise in their read-out, out-proj / fc2 write the
+    blocked stream + its row statistics, and no LayerNorm kernel runs between them (only in front of block 0 and behind the
+    last block)."""
     import torch
     from mio import ops
+    from mio._nn import ResidualStream
 
-    blk = model.h[0]
     B, S, d = x.shape
+    blk0, blk = model.h[0], model.h[1 if len(model.h) > 1 else 0]
     H = blk.attn.num_attention_heads
     D = d // H
     M = B * S
-    wqkv, bqkv = blk.attn.qkv_proj.weight, blk.attn.qkv_proj.bias
+    dt = x.dtype
     wo, bo = blk.attn.o_proj.weight, blk.attn.o_proj.bias
     w1, b1 = blk.mlp.mlp.fc1.weight, blk.mlp.mlp.fc1.bias
     w2, b2 = blk.mlp.mlp.fc2.weight, blk.mlp.mlp.fc2.bias
+    wqkv, bqkv = blk.attn.qkv_proj.weight, blk.attn.qkv_proj.bias
     I = w1.shape[0]
+    fold = (not getattr(model, "no_ln_fold", False)) and len(model.h) > 1 and all(b_.stream_ok(B, S, dt) for b_ in model.h)
+    out = {}
+    kpre = (D <= 64 and d % 128 == 0 and ops.col_scale_ok(M, 3 * d, d) and ops.fa3_k_prescaled_ok(B, S, S, H, D, 3 * d, 3 * d))
+    cs = (d, 2 * d, 1.4426950408889634 / D ** 0.5) if kpre else None
+    if fold:
+        with torch.no_grad():
+            s1 = blk0(x, stream_out=True)  # the residual stream as block 1 receives it: blocked + row statistics
+        assert isinstance(s1, ResidualStream)
+        ac, mc = blk.attn._cast, blk.mlp.mlp._cast
+        wq_f, bq_f = ac.get_ln_folded(blk.attn.qkv_proj, blk.ln_1, dt)
+        w1_f, b1_f = mc.get_ln_folded(blk.mlp.mlp.fc1, blk.ln_2, dt)
+        wo_b, w2_b = ops.block_weight(wo), ops.block_weight(w2)
+        qkv, _ = ops.gemm_ln(s1.blocked, wq_f, bq_f, M=M, N=3 * d, K=d, x_blocked=True, ln_stats=s1.stats, eps=blk.ln_1.eps, col_scale=cs)
+        qkv = qkv.view(B, S, 3 * d)
+        q, k, v = (qkv[:, :, i * d:(i + 1) * d].view(B, S, H, D) for i in range(3))
+        ctx = ops.fa3_fwd(q, k, v, causal=True, k_prescaled=True, out_blocked=True)
+        a_b, a_st = ops.gemm_ln(ctx, wo_b, bo, M=M, N=d, K=d, x_blocked=True, residual=s1.blocked, res_blocked=True,
+                                out_blocked=True, stats_out=True)
+        t = _events_ms(lambda: ops.fa3_fwd(q, k, v, causal=True, k_prescaled=True, out_blocked=True), iters)
+        out["fa3_fwd5_kernel<bf16,causal>"] = dict(ms=t, launches=1, flops=2.0 * B * S * (S + 1) * d)
+        t = _events_ms(lambda: ops.gemm_ln(s1.blocked, wq_f, bq_f, M=M, N=3 * d, K=d, x_blocked=True, ln_stats=s1.stats,
+                                           eps=blk.ln_1.eps, col_scale=cs), iters)
+        out["gemm8w_kernel<bf16,none,ln-fold> (qkv)"] = dict(ms=t, launches=1, flops=2.0 * M * d * 3 * d)
+
+        def mlp():
+            h, _ = ops.gemm_ln(a_b, w1_f, b1_f, M=M, N=I, K=d, activation="gelu", x_blocked=True, out_blocked=True,
+                               ln_stats=a_st, eps=blk.ln_2.eps)
+            ops.gemm_ln(h, w2_b, b2, M=M, N=d, K=I, x_blocked=True, residual=a_b, res_blocked=True, out_blocked=True, stats_out=True)
+
+        t = _events_ms(mlp, iters)
+        out["fused_mlp: gemm8w_kernel<bf16,gelu_tanh,ln-fold> + gemm8w_kernel<bf16,none,residual,ln-stats>"] = dict(
+            ms=t, launches=2, flops=4.0 * M * d * I, combined=True)  # two different kernels: not a roofline candidate
+        t = _events_ms(lambda: ops.gemm_ln(ctx, wo_b, bo, M=M, N=d, K=d, x_blocked=True, residual=s1.blocked, res_blocked=True,
+                                           out_blocked=True, stats_out=True), iters)
+        out["gemm8w_kernel<bf16,none,residual,ln-stats> (out-proj)"] = dict(ms=t, launches=1, flops=2.0 * M * d * d)
+        t = _events_ms(lambda: ops.layernorm(x, blk0.ln_1.weight, blk0.ln_1.bias), iters)
+        # two LayerNorm launches per FORWARD are left (block 0's ln_1, ln_f): their per-layer share
+        out["layernorm_kernel<bf16> (2 launches per forward / L)"] = dict(ms=2 * t / len(model.h), launches=2,
+                                                                         bytes=2 * 2.0 * M * d * 2 / len(model.h))
+        return out
     # weights in the blocked layout, as the modules hand them over at this size (mio/_nn.py linear)
     wqkv_b, wo_b, w1_b, w2_b = (ops.block_weight(t) for t in (wqkv, wo, w1, w2))
     ln1 = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
     # as FlashSelfAttention runs it: the QKV projection's epilogue scales the K columns by softmax_scale * log2(e) in fp32
     # (one rounding) and the attention kernel is told so (k_prescaled) where both kernels support it
-    kpre = (D <= 64 and d % 128 == 0 and ops.col_scale_ok(M, 3 * d, d) and ops.fa3_k_prescaled_ok(B, S, S, H, D, 3 * d, 3 * d))
-    cs = (d, 2 * d, 1.4426950408889634 / D ** 0.5) if kpre else None
     qkv = ops.gemm_bias_act(ln1, wqkv, bqkv, w_blocked=wqkv_b, col_scale=cs)
     q = qkv[:, :, :d].view(B, S, H, D)
     k = qkv[:, :, d:2 * d].view(B, S, H, D)
@@ -140,7 +183,6 @@ def kernel_rooflines(model, x, iters=10):
         att = ops.gemm_bias_act(ctx, wo, bo, residual=x)
     ln2 = ops.layernorm(att, blk.ln_2.weight, blk.ln_2.bias)
     o3, o1 = torch.empty_like(qkv), torch.empty_like(att)
-    out = {}
     t = _events_ms(lambda: ops.fa3_fwd(q, k, v, causal=True, k_prescaled=kpre, out_blocked=oblk), iters)
     out["fa3_fwd5_kernel<bf16,causal>" if kpre else "fa3_fwd4_kernel<bf16,causal>"] = dict(ms=t, launches=1, flops=2.0 * B * S * (S + 1) * d)
 

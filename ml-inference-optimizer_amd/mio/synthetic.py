@@ -39,7 +39,10 @@ class Block(nn.Module):
 
     def stream_ok(self, B: int, S: int, dtype: torch.dtype) -> bool:
         """The block can run with both LayerNorms folded into the GEMMs around them (mio._nn.ResidualStream)."""
-        return self.attn.stream_ok(B, S, dtype, self.ln_1) and self.mlp.stream_ok(B, S, dtype, self.ln_2)
+        a_ok, m_ok = getattr(self.attn, "stream_ok", None), getattr(self.mlp, "stream_ok", None)  # converted sub-layers (tensor /
+        if a_ok is None or m_ok is None:                                                           # sequence parallel) have none
+            return False
+        return a_ok(B, S, dtype, self.ln_1) and m_ok(B, S, dtype, self.ln_2)
 
     def forward(self, x, stream_out: bool = False, fold: bool = True):
         """x: [B, S, d] tensor or the ResidualStream of the previous block (fold=False: every LayerNorm as its own kernel).  Where stream_ok(): ln_2 is folded into the output

@@ -290,7 +290,11 @@ def test_block_prenorm_equals_decomposed():
         blk.ln_1.weight.add_(1.0)
         blk.ln_2.weight.add_(1.0)
         x = torch.randn(B, S, d, device=DEV, dtype=torch.bfloat16)
-        y = blk(x)
+        y = blk(x, fold=False)
         a = blk.attn(blk.ln_1(x), residual=x)
         ref = blk.mlp(blk.ln_2(a), residual=a)
+        y_fold = blk(x)   # ln_2 folded into the GEMMs around it (ResidualStream): other roundings, same values
     assert torch.equal(y, ref)
+    assert blk.stream_ok(B, S, torch.bfloat16)
+    rel = ((y_fold.float() - ref.float()).abs().mean() / ref.float().abs().mean()).item()
+    assert rel < 3e-3, rel
