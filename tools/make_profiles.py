@@ -27,8 +27,9 @@ def short(name):
         vals = [v for _, v in ints]
         if k in ("gemm4w16_kernel", "gemm4w16p_kernel"):
             return f"{k}<{dt},{ACT.get(vals[0], vals[0])}>"
-        if k == "gemm8w_kernel":  # <T, ACT, RES, VAR>
-            return f"{k}<{dt},{ACT.get(vals[0], vals[0])}{',residual' if vals[1] == '1' else ''}>"
+        if k == "gemm8w_kernel":  # <T, ACT, RES, VAR, FOLD>: FOLD 1 = LayerNorm applied in the read-out, 2 = row statistics written
+            fold = {"1": ",ln-fold", "2": ",ln-stats"}.get(vals[3] if len(vals) > 3 else "0", "")
+            return f"{k}<{dt},{ACT.get(vals[0], vals[0])}{',residual' if vals[1] == '1' else ''}{fold}>"
         if k == "gemm_bias_act_kernel":
             return f"{k}<{dt},{ACT.get(vals[-1], vals[-1])}>"
         if k in ("fa3_fwd_kernel", "fa3_fwd2_kernel"):
@@ -47,6 +48,11 @@ def short(name):
         return "fa3_fwd4_kernel<bf16,causal,k_prescaled>"
     if re.match(r"(?:void )?fa3_fwd5_kernel<", name):  # the benchmark launches <__bf16, true>
         return "fa3_fwd5_kernel<bf16,causal>"
+    m = re.match(r"(?:void )?gemm8w_kernel<bool _Accum, int, E(Lb0E)?(?:, (true|false))?, (\d+), (\d+)>", name)
+    if m:  # rocprofv3's partly demangled <__bf16, ACT, RES, VAR, FOLD>: "E, false, 0, 1" = gelu_tanh (ACT 1), "ELb0E, 0, 0" = swiglu (ACT 5)
+        fold = {"1": ",ln-fold", "2": ",ln-stats"}.get(m.group(4), "")
+        act = "swiglu" if m.group(1) else "gelu_tanh"
+        return f"gemm8w_kernel<bf16,{act}{',residual' if m.group(2) == 'true' else ''}{fold}>"
     m = re.match(r"(?:void )?(\w+_kernel)<bool _Accum, int, E(?:, (\d+))?", name)
     if m:  # rocprofv3 mis-demangles <__bf16, 1, ...>: only the gelu_tanh (ACT = 1) GEMMs of the benchmark show up so
         return f"{m.group(1)}<bf16,gelu_tanh>"
