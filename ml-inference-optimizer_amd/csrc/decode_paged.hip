@@ -49,10 +49,10 @@ static inline int dec_nsplit_gqa(int64_t units, int max_ctx, int bs, int D = 128
 // (5.7-5.9 TB/s at MHA) and fall off from there -- tools/dbg/dec_gqa_small_qn.py, shipped-before vs this kernel: 2 vectors
 // 5.52 -> 6.16 TB/s (D 128, B 64), 2.31 -> 3.25 (D 64, B 8), 5.46 -> 5.25 (D 64, two query positions: the one loss); 3 vectors
 // 2.36 -> 5.75; 4 vectors 3.32 -> 5.48 and 1.67 -> 4.89 at B 1 x ctx 131072; 8 vectors 1.04 -> 5.4-5.7.  With one vector it
-// is 8 % slower at D 64 (5.20 vs 5.68) and 2 % faster at D 128: left to the row kernels.
+// is 8 % slower at D 64 (5.20 vs 5.68: left to the row kernels) and 2 % faster at D 128 (taken).
 static inline bool dec_gqa_ok(int B, int H, int Hkv, int q_len, int D, int max_ctx, int bs, const int64_t* os, const void* o) {
   const int qn = (H / Hkv) * q_len;
-  if (qn < 2 || qn > 16) return false;
+  if (qn > 16 || (qn < 2 && D != 128)) return false;  // one query vector per key: only at D 128 (5.90 -> 6.05, 5.49 -> 5.62 TB/s)
   if (D != 64 && D != 128) return false;
   if (max_ctx < 1) return false;
   if (os[0] % 8 != 0 || os[1] % 8 != 0 || os[2] % 8 != 0 || !mio_aligned16(o)) return false;  // 16-byte output stores

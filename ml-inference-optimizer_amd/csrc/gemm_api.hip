@@ -358,7 +358,8 @@ extern "C" int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, c
                               void* stream) {
   const bool xb = (flags & MIO_GEMM_X_BLOCKED) != 0, yb = (flags & MIO_GEMM_Y_BLOCKED) != 0, rb = (flags & MIO_GEMM_RES_BLOCKED) != 0;
   MIO_CHECK(x && wb && y, "mio_gemm_ln_bw: x, wb, y must be non-null");
-  MIO_CHECK(M > 0 && N > 0 && K > 0, "mio_gemm_ln_bw: bad sizes");
+  MIO_CHECK(M >= 0 && N > 0 && K > 0, "mio_gemm_ln_bw: bad sizes");
+  if (M == 0) return 0;
   MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_gemm_ln_bw: dtype must be bf16 or fp16");
   MIO_CHECK(act >= MIO_ACT_NONE && act < MIO_ACT_SWIGLU, "mio_gemm_ln_bw: unknown / unsupported activation");
   MIO_CHECK((flags & ~7) == 0, "mio_gemm_ln_bw: unknown flag");
