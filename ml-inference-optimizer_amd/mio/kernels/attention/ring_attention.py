@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ..._nn import CastCache, compute_dtype, linear
+from ..._nn import CastCache, ResidualStream, compute_dtype, linear
 
 
 @dataclass
@@ -140,10 +140,56 @@ class RingCrossAttention(RingAttention):
         self.out_proj = nn.Linear(hidden_size, hidden_size, bias=True)
         self.attention_dropout = nn.Dropout(config.attention_dropout)
 
+    def stream_ok(self, B: int, Sq: int, dtype: torch.dtype, pre_norm: Optional[nn.LayerNorm]) -> bool:
+        """True iff forward(...) can take / return the query-side residual stream as a ResidualStream (mio._nn): the folded
+        GEMMs on the query projection (LayerNorm in its read-out) and the output projection (blocked stream + row statistics)."""
+        d, M = self.hidden_size, B * Sq
+        if dtype not in (torch.float16, torch.bfloat16) or pre_norm is None or pre_norm.weight is None or ops.NO_BLOCKED_X:
+            return False
+        if compute_dtype(self.config.precision, torch.empty(0, dtype=dtype)) != dtype or tuple(pre_norm.normalized_shape) != (d,):
+            return False
+        return ops.gemm_ln_ok(M, d, d, "none", fold_in=True) and ops.gemm_ln_ok(M, d, d, "none", stats_out=True)
+
     def forward(self, query_states: torch.Tensor, key_value_states: torch.Tensor,
-                attention_mask: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                attention_mask: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                pre_norm: Optional[nn.LayerNorm] = None, stream_out: bool = False) -> torch.Tensor:
         """query_states [B,Sq,d], key_value_states [B,Sk,d], additive mask [B,1|H,Sq,Sk] (:442-499).
-        residual (not in the reference): added in the out-projection's epilogue."""
+        residual (not in the reference): added in the out-projection's epilogue.
+        pre_norm (not in the reference): a LayerNorm applied to query_states first.  With it, query_states may be a
+        ResidualStream and stream_out=True returns one (where stream_ok()): the residual is then the stream itself, the
+        LayerNorm runs in the query projection's read-out and the output projection writes the new stream blocked + its row
+        statistics (ops.gemm_ln)."""
+        if isinstance(query_states, ResidualStream) or stream_out:
+            B, Sq, d = query_states.shape
+            if (residual is not None and residual is not query_states) or not self.stream_ok(B, Sq, query_states.dtype, pre_norm):
+                raise ValueError("the ResidualStream form needs pre_norm, residual = the query input itself and a size with stream_ok()")
+            dt, c, M = query_states.dtype, self._cast, B * Sq
+            self._check(key_value_states)
+            xkv = key_value_states if key_value_states.dtype == dt else key_value_states.to(dt)
+            if isinstance(query_states, ResidualStream):
+                wfb, bfold = c.get_ln_folded(self.q_proj, pre_norm, dt)
+                q2, _ = ops.gemm_ln(query_states.blocked, wfb, bfold, M=M, N=d, K=d, x_blocked=True, ln_stats=query_states.stats,
+                                    eps=pre_norm.eps)
+                res, res_blocked = query_states.blocked, True
+            else:
+                xn = ops.layernorm(query_states, c.get(pre_norm.weight, dt), c.get(pre_norm.bias, dt), pre_norm.eps)
+                q2 = linear(xn, self.q_proj, c, dt)
+                res, res_blocked = query_states.reshape(M, d), False
+            q = self._heads(q2.view(B, Sq, d))
+            Sk = xkv.shape[1]
+            kpre = (attention_mask is None and d % 128 == 0 and d % 32 == 0
+                    and ops.fa3_k_prescaled_ok(B, Sq, Sk, self.num_attention_heads, self.head_dim, d, d)
+                    and ops.blocked_weight_ok(B * Sk, d, d) and ops.col_scale_ok(B * Sk, d, d))
+            cs = (0, d, self.scale * 1.4426950408889634) if kpre else None
+            k = self._heads(linear(xkv, self.k_proj, c, dt, col_scale=cs))
+            v = self._heads(linear(xkv, self.v_proj, c, dt))
+            ctx = ops.ring_attention_forward(q, k, v, attention_mask, k_prescaled=kpre)
+            y, st = ops.gemm_ln(ctx.reshape(M, d), c.get_blocked(self.out_proj.weight, dt), c.get(self.out_proj.bias, dt), M=M, N=d,
+                                K=d, residual=res, res_blocked=res_blocked, out_blocked=stream_out, stats_out=stream_out)
+            return ResidualStream(y, st, (B, Sq, d)) if stream_out else y.view(B, Sq, d)
+        if pre_norm is not None:
+            query_states = ops.layernorm(query_states, self._cast.get(pre_norm.weight, query_states.dtype),
+                                         self._cast.get(pre_norm.bias, query_states.dtype), pre_norm.eps)
         in_dtype = query_states.dtype
         dt = self._check(query_states)
         self._check(key_value_states)

@@ -72,7 +72,21 @@ class CrossBlock(nn.Module):
         self.ln_2 = FusedLayerNorm(d)
         self.mlp = FusedTransformerMLP(d, I, activation, FusedMLPConfig(precision=precision))
 
-    def forward(self, x: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+    def stream_ok(self, B: int, S: int, dtype: torch.dtype) -> bool:
+        a_ok, m_ok = getattr(self.attn, "stream_ok", None), getattr(self.mlp, "stream_ok", None)
+        if a_ok is None or m_ok is None:
+            return False
+        return a_ok(B, S, dtype, self.ln_1) and m_ok(B, S, dtype, self.ln_2)
+
+    def forward(self, x, context: torch.Tensor, stream_out: bool = False, fold: bool = True):
+        """x: [B, S, d] tensor or the previous block's ResidualStream; the LayerNorms are folded into the GEMMs around them where
+        stream_ok() (Block.forward)."""
+        B, S, _ = x.shape
+        if isinstance(x, ResidualStream) or (fold and self.stream_ok(B, S, x.dtype)):
+            a = self.attn(x, context, residual=x, pre_norm=self.ln_1, stream_out=True)
+            return self.mlp(a, residual=a, pre_norm=self.ln_2, stream_out=stream_out)
+        if stream_out:
+            raise ValueError("stream_out needs a size / dtype with stream_ok()")
         x = self.attn(self.ln_1(x), context, residual=x)
         return self.mlp(x, residual=x, pre_norm=self.ln_2)
 
@@ -85,6 +99,7 @@ class CrossAttentionStack(nn.Module):
         super().__init__()
         I = intermediate_size or 4 * hidden_size
         self.h = nn.ModuleList([CrossBlock(hidden_size, num_heads, I, precision) for _ in range(num_layers)])
+        self.no_ln_fold = False  # True: every LayerNorm runs as its own kernel (A/B of the fold)
         g = torch.Generator().manual_seed(seed)
         with torch.no_grad():
             for m in self.modules():
@@ -94,8 +109,11 @@ class CrossAttentionStack(nn.Module):
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
-        for blk in self.h:
-            x = blk(x, context)
+        B, S, _ = x.shape
+        fold = not self.no_ln_fold and all(blk.stream_ok(B, S, x.dtype) for blk in self.h)
+        last = len(self.h) - 1
+        for i, blk in enumerate(self.h):
+            x = blk(x, context, stream_out=(fold and i < last), fold=fold)
         return x
 
 

@@ -665,6 +665,34 @@ def test_c5_cross_block(B, Sk):
             chain(torch.bfloat16).view(-1, d))
 
 
+def test_c5_stack_layernorm_folded():
+    """The C5 stack as bench.py runs it (B 8, Sq = Sk = 4096, d 1280 -> five statistic slots, I 5120), two blocks: every LayerNorm
+    between GEMMs folded into them (the query projection of block 2 reads block 1's blocked stream) against the same stack with
+    separate LayerNorm kernels; non-trivial LayerNorm parameters and a stream with a mean."""
+    from mio.synthetic import CrossAttentionStack
+    B, S, d, H, I = 8, C5["S"], C5["d"], C5["H"], C5["I"]
+    stack = CrossAttentionStack(d, H, 2, I, "bf16", seed=3)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        for m in stack.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.02)
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.copy_(1 + 0.1 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+    stack = stack.to(device=DEV, dtype=torch.bfloat16).eval()
+    x, = _c2_inputs(50, (B, S, d))
+    x = x + 0.2
+    ctx_in, = _c2_inputs(51, (B, S, d))
+    assert all(blk.stream_ok(B, S, torch.bfloat16) for blk in stack.h)
+    y = stack(x, ctx_in)
+    stack.no_ln_fold = True
+    y_sep = stack(x, ctx_in)
+    rel, mx = _rel(y, y_sep)
+    PARITY["c5_stack 2 blocks B8 S4096 d1280: LayerNorms folded vs separate kernels"] = dict(rel_diff=rel, max_abs_diff=mx)
+    assert rel < 3e-3, rel
+
+
 def test_c5_cross_attention_k_prescaled():
     """RingCrossAttention at a size where the K projection runs the persistent GEMM: its epilogue hands over
     K * softmax_scale * log2(e) and the Dh 80 non-causal launch takes fa3_fwd3's k_prescaled form."""
