@@ -197,8 +197,9 @@ int mio_layernorm_fwd_bx(const void* x, const void* residual, const void* weight
  * flags: the operands in the blocked activation layout ((256-row, 32-column) blocks of 16 KiB, rows padded to 256; ld* ignored
  * for a blocked operand): x (as mio_gemm_bias_act_bw's x_blocked), y (what the next GEMM takes as blocked x), residual.
  * Shapes: mio_gemm_ln_ok(M, N, K, act, fold_in, stats_out) != 0 (blocked-weight shapes; fold_in: K % 256 == 0, K <= 2048, act
- * none / gelu_tanh; stats_out: N % 256 == 0, N <= 2048, act none).  Without ln_stats and stats_out it is mio_gemm_bias_act_bw
- * (+ column scale) with blocked y / residual. */
+ * none / gelu_tanh / swiglu; stats_out: N % 256 == 0, N <= 2048, act none).  Without ln_stats and stats_out it is
+ * mio_gemm_bias_act_bw (+ column scale) with blocked y / residual.  act == MIO_ACT_SWIGLU: wb is mio_weight_block_glu of the two
+ * folded weights (gate, up), bias the up bias, bias_gate the gate bias, N the number of OUTPUT columns (I). */
 #define MIO_GEMM_X_BLOCKED 1
 #define MIO_GEMM_Y_BLOCKED 2
 #define MIO_GEMM_RES_BLOCKED 4
@@ -208,7 +209,7 @@ int32_t mio_gemm_ln_ok(int64_t M, int32_t N, int32_t K, int32_t act, int32_t fol
  * = w * gamma - mean_k(w * gamma) (rounded once), bias_out [N] = bias + w beta.  One-time weight preparation. */
 int mio_ln_fold_weight(const void* w, int64_t ldw, const void* gamma, const void* beta, const void* bias, void* w_scaled,
                        void* bias_out, int32_t N, int32_t K, int32_t dtype, void* stream);
-int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, const void* residual, void* y, int64_t M, int32_t N, int32_t K,
+int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, const void* bias_gate, const void* residual, void* y, int64_t M, int32_t N, int32_t K,
                    int64_t ldx, int64_t ldy, int64_t ldr, int32_t act, int32_t dtype, int32_t flags, const float* ln_stats,
                    float ln_eps, float* stats_out, int32_t cs_lo, int32_t cs_hi, float cs_val, void* stream);
 

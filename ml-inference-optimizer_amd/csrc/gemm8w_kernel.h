@@ -84,7 +84,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
   constexpr int ONT = WN / 16;         // output column tiles per wave
   constexpr int NCH = 4 * ONT;         // 16-byte output chunks per lane and tile: chunk j = (row pair j / ONT, column tile j % ONT)
   static_assert(!(GLU && RES), "no residual on the gated stage");
-  static_assert(FOLD == 0 || !GLU, "the LayerNorm fold is not built for the gated stage");
+  static_assert(FOLD != 2 || !GLU, "the gated stage has no residual epilogue, hence no row statistics");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -394,10 +394,23 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
             const f32x4_t au = acc[2 * mtp][nt + 2], bu = acc[2 * mtp + 1][nt + 2];
             const X4 uv = __builtin_bit_cast(X4, bq[nt + 2]);
             const f32x2_t u01 = {(float)uv[0], (float)uv[1]}, u23 = {(float)uv[2], (float)uv[3]};
-            a01 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>((f32x2_t){a[0], a[1]} + b01) * ((f32x2_t){au[0], au[1]} + u01);
-            a23 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>((f32x2_t){a[2], a[3]} + b23) * ((f32x2_t){au[2], au[3]} + u23);
-            c01 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>((f32x2_t){b[0], b[1]} + b01) * ((f32x2_t){bu[0], bu[1]} + u01);
-            c23 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>((f32x2_t){b[2], b[3]} + b23) * ((f32x2_t){bu[2], bu[3]} + u23);
+            // (va / vb: the gate's pre-activation values; the up half takes the same rstd under FOLD 1)
+            f32x2_t ua01, ua23, ub01, ub23;
+            if constexpr (FOLD == 1) {
+              ua01 = (f32x2_t){au[0], au[1]} * rsA + u01;
+              ua23 = (f32x2_t){au[2], au[3]} * rsA + u23;
+              ub01 = (f32x2_t){bu[0], bu[1]} * rsB + u01;
+              ub23 = (f32x2_t){bu[2], bu[3]} * rsB + u23;
+            } else {
+              ua01 = (f32x2_t){au[0], au[1]} + u01;
+              ua23 = (f32x2_t){au[2], au[3]} + u23;
+              ub01 = (f32x2_t){bu[0], bu[1]} + u01;
+              ub23 = (f32x2_t){bu[2], bu[3]} + u23;
+            }
+            a01 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>(va01) * ua01;
+            a23 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>(va23) * ua23;
+            c01 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>(vb01) * ub01;
+            c23 = gemm_act2<MIO_ACT_SILU, SCALAR_ACT>(vb23) * ub23;
           } else {
             a01 = gemm_act2<ACT, SCALAR_ACT>(va01) * cs2;
             a23 = gemm_act2<ACT, SCALAR_ACT>(va23) * cs2;

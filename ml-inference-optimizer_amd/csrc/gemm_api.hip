@@ -301,6 +301,11 @@ extern "C" size_t mio_ln_stats_bytes(int64_t M, int32_t width) {
 
 extern "C" int32_t mio_gemm_ln_ok(int64_t M, int32_t N, int32_t K, int32_t act, int32_t fold_in, int32_t stats_out) {
   if (mio_gemm_impl() != 0) return 0;
+  if (act == MIO_ACT_SWIGLU) {  // the gated stage (interleaved gate / up blocked weight, 256 x 128 output tiles): consumer form only
+    const bool big = ((M + 255) / 256) * (int64_t)((N + 127) / 128) >= 256;
+    return (big && !stats_out && N % 128 == 0 && K >= 128 && (int64_t)K * 512 < 0x7fffffff && (int64_t)N * 512 < 0x7fffffff &&
+            (!fold_in || (K % 256 == 0 && K / 256 <= G8_LN_SLOTS_MAX_HOST)) && K % 32 == 0) ? 1 : 0;
+  }
   if (!gemm_blocked_w_ok(M, N, K, act) || N % 32 != 0) return 0;
   if (fold_in && (K % 256 != 0 || K / 256 > G8_LN_SLOTS_MAX_HOST || (act != MIO_ACT_NONE && act != MIO_ACT_GELU_TANH))) return 0;
   if (stats_out && (N % 256 != 0 || N / 256 > G8_LN_SLOTS_MAX_HOST || act != MIO_ACT_NONE || fold_in)) return 0;
@@ -352,7 +357,7 @@ extern "C" int mio_ln_fold_weight(const void* w, int64_t ldw, const void* gamma,
   return 0;
 }
 
-extern "C" int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, const void* residual, void* y, int64_t M, int32_t N,
+extern "C" int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, const void* bias_gate, const void* residual, void* y, int64_t M, int32_t N,
                               int32_t K, int64_t ldx, int64_t ldy, int64_t ldr, int32_t act, int32_t dtype, int32_t flags,
                               const float* ln_stats, float ln_eps, float* stats_out, int32_t cs_lo, int32_t cs_hi, float cs_val,
                               void* stream) {
@@ -361,8 +366,11 @@ extern "C" int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, c
   MIO_CHECK(M >= 0 && N > 0 && K > 0, "mio_gemm_ln_bw: bad sizes");
   if (M == 0) return 0;
   MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_gemm_ln_bw: dtype must be bf16 or fp16");
-  MIO_CHECK(act >= MIO_ACT_NONE && act < MIO_ACT_SWIGLU, "mio_gemm_ln_bw: unknown / unsupported activation");
+  MIO_CHECK(act >= MIO_ACT_NONE && act <= MIO_ACT_SWIGLU, "mio_gemm_ln_bw: unknown activation");
   MIO_CHECK((flags & ~7) == 0, "mio_gemm_ln_bw: unknown flag");
+  MIO_CHECK(act == MIO_ACT_SWIGLU || bias_gate == nullptr, "mio_gemm_ln_bw: bias_gate belongs to the gated stage (act == SWIGLU)");
+  MIO_CHECK(act != MIO_ACT_SWIGLU || residual == nullptr, "mio_gemm_ln_bw: the gated stage takes no residual");
+  MIO_CHECK(mio_aligned16(bias_gate), "mio_gemm_ln_bw: pointers must be 16-byte aligned");
   MIO_CHECK(mio_gemm_ln_ok(M, N, K, act, ln_stats != nullptr, stats_out != nullptr),
             "mio_gemm_ln_bw: this shape / activation does not take the folded kernels (mio_gemm_ln_ok == 0)");
   MIO_CHECK(ln_stats == nullptr || residual == nullptr, "mio_gemm_ln_bw: the consumer form takes no residual");
@@ -383,9 +391,9 @@ extern "C" int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, c
             "mio_gemm_ln_bw: [cs_lo, cs_hi) must be multiples of 128 inside [0, N], without a residual");
   GemmDev p;
   gemm_dev_defaults(p);
-  p.x = x; p.w = wb; p.bias = bias; p.res = residual; p.y = y;
+  p.x = x; p.w = wb; p.bias = bias; p.bias_g = bias_gate; p.res = residual; p.y = y;
   p.M = M; p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.ldr = ldr; p.N = N; p.K = K;
-  p.x_blk = xb ? 1 : 0; p.y_blk = yb ? 1 : 0; p.w_blk = 1; p.res_blk = rb ? 1 : 0;
+  p.x_blk = xb ? 1 : 0; p.y_blk = yb ? 1 : 0; p.w_blk = (act == MIO_ACT_SWIGLU) ? 2 : 1; p.res_blk = rb ? 1 : 0;
   p.cs_lo = cs_lo; p.cs_hi = cs_hi; p.cs_val = cs_val;
   p.ln_stats = ln_stats; p.ln_eps = ln_eps; p.ln_slots = ln_stats ? K / 256 : 0;
   p.stats_out = stats_out;

@@ -160,7 +160,10 @@ static int launch_act(const GemmDev& p, hipStream_t stream) {
   // Big tiles when they still fill the chip (>= 256 workgroups), else 128x128.
   constexpr bool GATE = (ACT == MIO_ACT_SWIGLU);
   if constexpr (GATE) {
-    if (p.w_blk == 2) return launch_8w<ACT, false>(p, stream);  // interleaved blocked gate / up weight (gemm_api.hip checked the shape)
+    if (p.w_blk == 2) {  // interleaved blocked gate / up weight (gemm_api.hip checked the shape)
+      if (p.ln_stats != nullptr) return launch_8w<ACT, false, 0, 1>(p, stream);  // LayerNorm applied in the read-out
+      return launch_8w<ACT, false>(p, stream);
+    }
     const int64_t big = ((p.M + 255) / 256) * ((p.N + 127) / 128);
     if (big >= 256) return launch_cfg<256, 128, 2, 4, ACT>(p, stream);
     return launch_cfg<128, 64, 2, 2, ACT>(p, stream);

@@ -94,6 +94,25 @@ def _get_ln_folded(self, lin: nn.Linear, ln: nn.LayerNorm, dtype: torch.dtype):
 CastCache.get_ln_folded = _get_ln_folded
 
 
+def _get_ln_folded_glu(self, gate: nn.Linear, up: nn.Linear, ln: nn.LayerNorm, dtype: torch.dtype):
+    """The SwiGLU pair behind LayerNorm `ln`: (interleaved blocked weight of the two folded weights, up bias', gate bias')."""
+    ps = (gate.weight, gate.bias, up.weight, up.bias, ln.weight, ln.bias)
+    key = tuple((None if t is None else (t.data_ptr(), t._version)) for t in ps) + (dtype, up.weight.device, "ln_fold_glu")
+    slot = ("fg", id(gate.weight), id(up.weight), id(ln.weight))
+    hit = self._c.get(slot)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    lw, lb = self.get(ln.weight, dtype), self.get(ln.bias, dtype)
+    wg, bg = ops.ln_fold_weight(self.get(gate.weight, dtype), lw, lb, self.get(gate.bias, dtype), blocked=False)
+    wu, bu = ops.ln_fold_weight(self.get(up.weight, dtype), lw, lb, self.get(up.bias, dtype), blocked=False)
+    t = (ops.block_weight_glu(wg, wu), bu, bg)
+    self._c[slot] = (key, t)
+    return t
+
+
+CastCache.get_ln_folded_glu = _get_ln_folded_glu
+
+
 class ResidualStream:
     """The residual stream between two sub-layers as the folded kernels hand it on (ops.gemm_ln): `blocked` is the
     [ceil(M/256)*256, d] tensor in the blocked activation layout, `stats` the (sum, sum of squares) row statistics its

@@ -60,14 +60,14 @@ class FusedMLP(nn.Module):
 
     def stream_ok(self, B: int, S: int, dtype: torch.dtype, pre_norm: Optional[nn.LayerNorm]) -> bool:
         """True iff forward(...) can take (and return) the residual stream as a ResidualStream at this size (ops.gemm_ln_ok on
-        both GEMMs; GELU-tanh or no activation -- the gated stage has no folded form)."""
+        both GEMMs; tanh-GELU or SwiGLU)."""
         act = self._kernel_activation()
         d, I, M = self.fc1.in_features, self.fc1.out_features, B * S
         if dtype not in (torch.float16, torch.bfloat16) or pre_norm is None or pre_norm.weight is None or ops.NO_BLOCKED_X:
             return False
         if compute_dtype(self.config.precision, torch.empty(0, dtype=dtype)) != dtype:
             return False  # the stream form runs in the stream's dtype
-        if act != "gelu" or tuple(pre_norm.normalized_shape) != (d,) or self.fc2.out_features != d:
+        if act not in ("gelu", "swiglu") or tuple(pre_norm.normalized_shape) != (d,) or self.fc2.out_features != d:
             return False
         if self.training and self.dropout is not None:
             return False
@@ -80,9 +80,12 @@ class FusedMLP(nn.Module):
         c, act = self._cast, self._kernel_activation()
         B, S, d = x.shape
         dt, M, I = x.dtype, B * S, self.fc1.out_features
-        wfb, bfold = c.get_ln_folded(self.fc1, pre_norm, dt)
+        if act == "swiglu":
+            wfb, bfold, bgate = c.get_ln_folded_glu(self.fc1_gate, self.fc1, pre_norm, dt)
+        else:
+            (wfb, bfold), bgate = c.get_ln_folded(self.fc1, pre_norm, dt), None
         h, _ = ops.gemm_ln(x.blocked, wfb, bfold, M=M, N=I, K=d, activation=act, x_blocked=True, out_blocked=True,
-                           ln_stats=x.stats, eps=pre_norm.eps)
+                           ln_stats=x.stats, eps=pre_norm.eps, bias_gate=bgate)
         y, st = ops.gemm_ln(h, c.get_blocked(self.fc2.weight, dt), c.get(self.fc2.bias, dt), M=M, N=d, K=I, x_blocked=True,
                             residual=x.blocked, res_blocked=True, out_blocked=stream_out, stats_out=stream_out)
         return ResidualStream(y, st, (B, S, d)) if stream_out else y.view(B, S, d)

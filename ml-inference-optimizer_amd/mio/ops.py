@@ -456,10 +456,12 @@ def gemm_ln_ok(M: int, N: int, K: int, activation: str = "none", fold_in: bool =
     return not _NO_BLOCKED_W and bool(lib.mio_gemm_ln_ok(M, N, K, _ACT.get(activation, _lib.ACT_NONE), int(fold_in), int(stats_out)))
 
 
-def ln_fold_weight(w: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], bias: Optional[torch.Tensor]):
+def ln_fold_weight(w: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], bias: Optional[torch.Tensor],
+                   blocked: bool = True):
     """One-time preparation of a projection that sits behind a LayerNorm(gamma, beta): returns
     (blocked weight = gamma-scaled rows with their mean over k subtracted, bias' [N] = bias + w @ beta).  With the rows centred
-    x @ w'^T equals (x - mean(x)) @ (gamma * w)^T, so gemm_ln's read-out only multiplies by rstd and adds bias'."""
+    x @ w'^T equals (x - mean(x)) @ (gamma * w)^T, so gemm_ln's read-out only multiplies by rstd and adds bias'.
+    blocked=False returns the row-major [N, K] weight instead (the SwiGLU pair goes through block_weight_glu afterwards)."""
     _need_cuda(w, gamma)
     dt = _dtype_id(w)
     N, K = w.shape
@@ -471,7 +473,7 @@ def ln_fold_weight(w: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Te
     bout = torch.empty(N, dtype=w.dtype, device=w.device)
     check(lib.mio_ln_fold_weight(w.data_ptr(), w.stride(0), gamma.data_ptr(), _ptr(beta), _ptr(bias), ws.data_ptr(),
                                  bout.data_ptr(), N, K, dt, _stream()))
-    return block_weight(ws), bout
+    return (block_weight(ws) if blocked else ws), bout
 
 
 def ln_stats_shape(M: int, width: int):
@@ -481,7 +483,7 @@ def ln_stats_shape(M: int, width: int):
 def gemm_ln(x: torch.Tensor, w_blocked: torch.Tensor, bias: Optional[torch.Tensor], *, M: int, N: int, K: int,
             activation: str = "none", x_blocked: bool = False, residual: Optional[torch.Tensor] = None,
             res_blocked: bool = False, out_blocked: bool = False, ln_stats: Optional[torch.Tensor] = None,
-            eps: float = 1e-5, stats_out: bool = False, col_scale=None):
+            eps: float = 1e-5, stats_out: bool = False, col_scale=None, bias_gate: Optional[torch.Tensor] = None):
     """y = act(LN?(x) @ w^T + bias) (+ residual) on the 256-tile kernels with the LayerNorm folded in (module docstring of
     include/mio_hip.h, "LayerNorm folded into the GEMMs on either side of it").  Operands are [M, *] row-major 2-D tensors or,
     where the *_blocked flag says so, [ceil(M/256)*256, *] tensors in the blocked activation layout.
@@ -490,9 +492,12 @@ def gemm_ln(x: torch.Tensor, w_blocked: torch.Tensor, bias: Optional[torch.Tenso
       stats_out=True:     also returns the (sum, sum of squares) statistics of the rounded output rows.
     Returns (y, stats) -- stats is None unless stats_out."""
     _need_cuda(x, w_blocked)
-    if activation not in _ACT or _ACT[activation] == _lib.ACT_SWIGLU:
+    if activation not in _ACT:
         raise ValueError(f"Unsupported activation function: {activation}")
     act, dt = _ACT[activation], _dtype_id(x)
+    glu = act == _lib.ACT_SWIGLU  # w_blocked = block_weight_glu(gate', up'), bias = up bias, bias_gate = gate bias, N = I
+    if bias_gate is not None and not glu:
+        raise ValueError("bias_gate belongs to activation='swiglu'")
     fold = ln_stats is not None
     if not lib.mio_gemm_ln_ok(M, N, K, act, int(fold), int(stats_out)):
         raise ValueError("gemm_ln: this shape / activation does not take the folded kernels (gemm_ln_ok)")
@@ -511,10 +516,11 @@ def gemm_ln(x: torch.Tensor, w_blocked: torch.Tensor, bias: Optional[torch.Tenso
         return t2, t2.stride(0)
 
     x2, ldx = _operand(x, K, x_blocked, "x")
-    if w_blocked.dtype != x.dtype or w_blocked.device != x.device or not w_blocked.is_contiguous() or \
-            w_blocked.numel() != (N + 255) // 256 * 256 * K:
-        raise ValueError("w_blocked: expected ceil(N/256)*256*K contiguous elements of x's dtype on its device")
+    wn = (N + 127) // 128 * 256 * K if glu else (N + 255) // 256 * 256 * K
+    if w_blocked.dtype != x.dtype or w_blocked.device != x.device or not w_blocked.is_contiguous() or w_blocked.numel() != wn:
+        raise ValueError(f"w_blocked: expected {wn} contiguous elements of x's dtype on its device (swiglu: block_weight_glu)")
     _vec_ok(bias, N, x.dtype, "bias")
+    _vec_ok(bias_gate, N, x.dtype, "bias_gate")
     r2, ldr = (None, 0) if residual is None else _operand(residual, N, res_blocked, "residual")
     if fold:
         want = ln_stats_shape(M, K)
@@ -529,7 +535,7 @@ def gemm_ln(x: torch.Tensor, w_blocked: torch.Tensor, bias: Optional[torch.Tenso
     y = torch.empty(mp if out_blocked else M, N, dtype=x.dtype, device=x.device)
     st = torch.empty(ln_stats_shape(M, N), dtype=torch.float32, device=x.device) if stats_out else None
     flags = (1 if x_blocked else 0) | (2 if out_blocked else 0) | (4 if (res_blocked and residual is not None) else 0)
-    check(lib.mio_gemm_ln_bw(x2.data_ptr(), w_blocked.data_ptr(), _ptr(bias), _ptr(r2), y.data_ptr(), M, N, K, ldx, N, ldr,
+    check(lib.mio_gemm_ln_bw(x2.data_ptr(), w_blocked.data_ptr(), _ptr(bias), _ptr(bias_gate), _ptr(r2), y.data_ptr(), M, N, K, ldx, N, ldr,
                              act, dt, flags, _ptr(ln_stats), float(eps), _ptr(st), lo, hi, val, _stream()))
     return y, st
 

@@ -759,6 +759,33 @@ def test_gemm_ln_fold(dtype, act):
     assert torch.equal(o_blk, o_plain)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_ln_fold_swiglu(dtype):
+    """The consumer form of the LayerNorm fold on the gated stage: silu(LN(y) Wg^T + bg) * (LN(y) Wu^T + bu) with the two folded
+    weights interleaved in one blocked weight, the raw blocked stream + statistics of a producer as input, against the oracle."""
+    ops = _ops()
+    torch.manual_seed(21)
+    M, d, I = 16500, 1024, 2048
+    assert ops.gemm_ln_ok(M, I, d, "swiglu", fold_in=True)
+    x0 = torch.randn(M, d).to(dtype)
+    r0 = (torch.randn(M, d) * 1.5 + 0.4).to(dtype)
+    wp, bp = (torch.randn(d, d) * 0.03).to(dtype), (torch.randn(d) * 0.1).to(dtype)
+    gamma, beta = (1 + 0.2 * torch.randn(d)).to(dtype), (0.1 * torch.randn(d)).to(dtype)
+    wg, wu = ((torch.randn(I, d) * 0.03).to(dtype) for _ in range(2))
+    bg, bu = ((torch.randn(I) * 0.1).to(dtype) for _ in range(2))
+    dv = lambda t: t.to(DEV)
+    yb, st = ops.gemm_ln(dv(x0), ops.block_weight(dv(wp)), dv(bp), M=M, N=d, K=d, residual=dv(r0), out_blocked=True, stats_out=True)
+    wgf, bgf = ops.ln_fold_weight(dv(wg), dv(gamma), dv(beta), dv(bg), blocked=False)
+    wuf, buf = ops.ln_fold_weight(dv(wu), dv(gamma), dv(beta), dv(bu), blocked=False)
+    hb, _ = ops.gemm_ln(yb, ops.block_weight_glu(wgf, wuf), buf, M=M, N=I, K=d, activation="swiglu", x_blocked=True, out_blocked=True,
+                        ln_stats=st, bias_gate=bgf)
+    h = _unblock(hb, M, I)
+    rows = torch.cat([torch.arange(0, M, 67), torch.tensor([255, 256, 16383, 16384, M - 1])])
+    ln = oracle.layernorm(_unblock(yb, M, d)[rows].cpu(), gamma, beta, 1e-5).double()
+    want = torch.nn.functional.silu(ln @ wg.double().t() + bg.double()) * (ln @ wu.double().t() + bu.double())
+    _cmp(h[rows], want, dtype, "ln-fold consumer swiglu")
+
+
 def test_errors_raise_before_launch():
     ops = _ops()
     q = torch.randn(1, 8, 2, 64, dtype=torch.float16, device=DEV)

@@ -277,6 +277,27 @@ def test_composed_functional_entry_points():
     assert ops._infer_heads(1280, 0) == 20 and ops._infer_heads(1024, 0) == 16 and ops._infer_heads(96, 0) == 1
 
 
+def test_block_swiglu_layernorm_folded():
+    """synthetic.Block with the SwiGLU MLP at a size where the LayerNorms fold into the GEMMs (ResidualStream): ln_2 runs inside
+    the gated stage's read-out (interleaved gate / up weight, both halves scaled by rstd); against the same block with separate
+    LayerNorm kernels."""
+    from mio.synthetic import Block
+    torch.manual_seed(9)
+    d, H, I, B, S = 1024, 16, 2048, 4, 4096
+    blk = Block(d, H, I, causal=True, precision="bf16", activation="swiglu").to(DEV, torch.bfloat16).eval()
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.03)
+        blk.ln_1.weight.add_(1.0)
+        blk.ln_2.weight.add_(1.0)
+        x = torch.randn(B, S, d, device=DEV, dtype=torch.bfloat16) + 0.3
+        assert blk.stream_ok(B, S, torch.bfloat16)
+        y = blk(x)
+        ref = blk(x, fold=False)
+    rel = ((y.float() - ref.float()).abs().mean() / ref.float().abs().mean()).item()
+    assert rel < 3e-3, rel
+
+
 def test_block_prenorm_equals_decomposed():
     """synthetic.Block at a size where LayerNorm hands over in the blocked layout (pre_norm=) == the same block with
     the LayerNorms applied outside the modules (plain layout): same kernels, same arithmetic -> same bits."""
