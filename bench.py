@@ -200,6 +200,18 @@ def kernel_rooflines(model, x, iters=10):
     return out
 
 
+def _decode_traffic(kernel_substr):
+    """HBM fetch bytes per launch of a decode kernel from the committed PMC pass (profiles/r03_pmc_decode.json, tools/decode_pmc.py)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_decode.json")))
+        for k, v in d.items():
+            if kernel_substr in k:
+                return v["fetch_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def decode_leg(dt):
     """Paged decode step: B 64, H 16, D 64, context 4096, block 16 -- 1 GiB of K/V cache, streams from
     HBM.  Bound: HBM.  Algorithmic bytes = 2 * B * ctx * Hkv * D * 2 (every cached K and V element once)."""
@@ -220,6 +232,7 @@ def decode_leg(dt):
     return {"workload": f"paged decode q_len 1, B {Bd} H {Hd} D {Dd} ctx {ctx} block {bs} (random physical blocks)",
             "kernel": "decode_rows_kernel + decode_reduce_kernel", "bound": "hbm", "ms": ms, "achieved": gbs,
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "bytes_per_launch": nbytes,
+            "traffic": _decode_traffic("decode_rows_kernel"),
             "tokens_per_s": Bd / (ms * 1e-3)}
 
 
@@ -243,6 +256,7 @@ def decode_gqa_leg(dt):
     return {"workload": f"paged decode q_len 1, B {Bd} H {Hd} Hkv {Hkv} D {Dd} ctx {ctx} block {bs} (random physical blocks)",
             "kernel": "decode_gqa_kernel + decode_reduce_kernel", "bound": "hbm", "ms": ms, "achieved": gbs,
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "bytes_per_launch": nbytes,
+            "traffic": _decode_traffic("decode_gqa_kernel"),
             "tokens_per_s": Bd / (ms * 1e-3)}
 
 
