@@ -20,6 +20,7 @@ from mio.synthetic import GPT2ShapedStack
 B, S, d, H, L, I = 8, 4096, 1024, 16, 24, 4096
 dt = torch.bfloat16
 model = GPT2ShapedStack(d, H, L, I, causal=True, precision="bf16", seed=0).to("cuda", dt).eval()
+model.no_ln_fold = True  # this tool measured the ROW-MAJOR fold bound before the fold was built: separate LayerNorm kernels as mode A
 x = torch.randn(B, S, d, device="cuda", dtype=dt)
 real_prenorm = _nn.prenorm_linear
 real_ln = ops.layernorm
