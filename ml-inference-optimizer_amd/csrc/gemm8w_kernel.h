@@ -64,7 +64,7 @@ constexpr int G8_RS_OFF = G8_SMEM;  // consumer: per wave, rstd of its group's 1
 constexpr int G8_STAT_OFF = G8_RS_OFF + 8 * 512;
 constexpr int G8_CNT_OFF = G8_STAT_OFF + 2 * 8192;
 constexpr int G8_SMEM_FOLD = G8_CNT_OFF + 64;
-constexpr int G8_LN_SLOTS_MAX = 8;
+static_assert(GEMM_LN_SLOTS_MAX * 1024 <= 8192, "a group's statistics region holds GEMM_LN_SLOTS_MAX slots of 128 rows x 8 bytes");
 
 // VAR (timing-only ablations, diagnostic library): 4 = no prefetch issue in the loop, 16 = no counted wait,
 // 64 = every piece re-reads K-tile 0, 128 = in-kernel stamps (tools/gemm8_stamps.py), 256 = scalar activation math,

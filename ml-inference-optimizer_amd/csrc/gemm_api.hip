@@ -4,8 +4,6 @@
 
 #include "gemm_kernel.h"
 
-constexpr int G8_LN_SLOTS_MAX_HOST = 8;  // gemm8w_kernel.h G8_LN_SLOTS_MAX (the kernel header is not included here)
-
 extern template int gemm_launch<__bf16>(GemmDev, int, hipStream_t);
 extern template int gemm_launch<_Float16>(GemmDev, int, hipStream_t);
 
@@ -304,11 +302,11 @@ extern "C" int32_t mio_gemm_ln_ok(int64_t M, int32_t N, int32_t K, int32_t act, 
   if (act == MIO_ACT_SWIGLU) {  // the gated stage (interleaved gate / up blocked weight, 256 x 128 output tiles): consumer form only
     const bool big = ((M + 255) / 256) * (int64_t)((N + 127) / 128) >= 256;
     return (big && !stats_out && N % 128 == 0 && K >= 128 && (int64_t)K * 512 < 0x7fffffff && (int64_t)N * 512 < 0x7fffffff &&
-            (!fold_in || (K % 256 == 0 && K / 256 <= G8_LN_SLOTS_MAX_HOST)) && K % 32 == 0) ? 1 : 0;
+            (!fold_in || (K % 256 == 0 && K / 256 <= GEMM_LN_SLOTS_MAX)) && K % 32 == 0) ? 1 : 0;
   }
   if (!gemm_blocked_w_ok(M, N, K, act) || N % 32 != 0) return 0;
-  if (fold_in && (K % 256 != 0 || K / 256 > G8_LN_SLOTS_MAX_HOST || (act != MIO_ACT_NONE && act != MIO_ACT_GELU_TANH))) return 0;
-  if (stats_out && (N % 256 != 0 || N / 256 > G8_LN_SLOTS_MAX_HOST || act != MIO_ACT_NONE || fold_in)) return 0;
+  if (fold_in && (K % 256 != 0 || K / 256 > GEMM_LN_SLOTS_MAX || (act != MIO_ACT_NONE && act != MIO_ACT_GELU_TANH))) return 0;
+  if (stats_out && (N % 256 != 0 || N / 256 > GEMM_LN_SLOTS_MAX || act != MIO_ACT_NONE || fold_in)) return 0;
   return 1;
 }
 

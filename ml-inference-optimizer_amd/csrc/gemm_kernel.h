@@ -58,6 +58,8 @@ struct GemmDev {
   float ln_eps;
 };
 
+constexpr int GEMM_LN_SLOTS_MAX = 8;  // 256-column statistic slots a folded LayerNorm may span (row width <= 2048): LDS region of gemm8w_kernel
+
 static inline void gemm_dev_defaults(GemmDev& p) {
   p.wg = nullptr; p.bias = nullptr; p.bias_g = nullptr; p.res = nullptr;
   p.tiles_m = p.tiles_n = 0;
