@@ -311,12 +311,19 @@ extern "C" int32_t mio_gemm_ln_ok(int64_t M, int32_t N, int32_t K, int32_t act, 
 }
 
 // one workgroup per weight row: w_scaled[n][k] = T(w[n][k] * gamma[k] - mean_k(w[n][.] * gamma[.])) (the row mean is taken over
-// the unrounded products), bias_out[n] = T(bias[n] + sum_k w[n][k] * beta[k])
+// the unrounded products), bias_out[n] = T(bias[n] + sum_k w[n][k] * beta[k]).
+// The consumer's read-out relies on sum_k w_scaled[n][k] = 0 (that is what removes the activations' mean); after rounding to 16
+// bits the sum is off by ~sqrt(K / 12) ulp, and the product picks up mean(x) times that.  So the rounding DIRECTION of a few
+// elements is flipped (those whose exact value sits closest to the midpoint of its two neighbours: the flip leaves their own
+// error almost unchanged, weighed against how much of the sum it removes) until no flip brings the row sum closer to zero:
+// <= 64 greedy steps per row, one-time weight preparation.
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fold_weight_kernel(const T* __restrict__ w, int64_t ldw, const T* __restrict__ gamma,
                                                              const T* __restrict__ beta, const T* __restrict__ bias,
                                                              T* __restrict__ ws, T* __restrict__ bias_out, int K) {
+  constexpr int EPT = 8;  // elements per thread (K <= 2048)
   __shared__ float s_c[256], s_b[256];
+  __shared__ int s_i[256];
   const int n = blockIdx.x, t = threadIdx.x;
   float c = 0.f, bb = 0.f;
   for (int k = t; k < K; k += 256) {
@@ -335,15 +342,93 @@ __global__ __launch_bounds__(256) void ln_fold_weight_kernel(const T* __restrict
     __syncthreads();
   }
   const float mean = s_c[0] / (float)K;
-  for (int k = t; k < K; k += 256) ws[(int64_t)n * K + k] = (T)((float)w[(int64_t)n * ldw + k] * (float)gamma[k] - mean);
   if (t == 0) bias_out[n] = (T)((bias != nullptr ? (float)bias[n] : 0.f) + s_b[0]);
+  __syncthreads();
+  // rounded values (as 16-bit patterns) and their exact counterparts
+  uint16_t bits[EPT];
+  float exact[EPT];
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int k = t + 256 * e;
+    bits[e] = 0;
+    exact[e] = 0.f;
+    if (k < K) {
+      exact[e] = (float)w[(int64_t)n * ldw + k] * (float)gamma[k] - mean;
+      const T r = (T)exact[e];
+      bits[e] = __builtin_bit_cast(uint16_t, r);
+      sum += (float)r;
+    }
+  }
+  auto val = [](uint16_t b) { return (float)__builtin_bit_cast(T, b); };
+  for (int it = 0; it < 64; ++it) {
+    s_c[t] = sum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (t < s) s_c[t] += s_c[t + s];
+      __syncthreads();
+    }
+    const float eps = s_c[0];  // sum of the rounded row (the exact row sums to zero)
+    __syncthreads();
+    // this thread's best flip: moves the sum towards zero without overshooting past -eps, smallest growth of its own error
+    float best = 3.0e38f;
+    int best_e = -1;
+    uint16_t best_bits = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int k = t + 256 * e;
+      if (k >= K || (bits[e] & 0x7fff) == 0) continue;
+      const float cur = val(bits[e]);
+      // the neighbour on the other side of the exact value
+      const bool up = cur < exact[e];  // rounded down -> candidate is the next value up
+      const bool neg = (bits[e] & 0x8000) != 0;
+      const uint16_t nb = (uint16_t)((up != neg) ? bits[e] + 1 : bits[e] - 1);
+      const float nv = val(nb);
+      const float delta = nv - cur;
+      if (!(delta * eps < 0.f) || fabsf(eps + delta) >= fabsf(eps)) continue;
+      // what the flip takes off |sum| minus what it adds to the element's own error (lower = better; the reduction of s_b is a min)
+      const float cost = fmaxf(fabsf(nv - exact[e]) - fabsf(cur - exact[e]), 0.f) - (fabsf(eps) - fabsf(eps + delta));
+      if (cost < best) {
+        best = cost;
+        best_e = e;
+        best_bits = nb;
+      }
+    }
+    s_b[t] = best;
+    s_i[t] = t;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (t < s && s_b[t + s] < s_b[t]) {
+        s_b[t] = s_b[t + s];
+        s_i[t] = s_i[t + s];
+      }
+      __syncthreads();
+    }
+    const bool any = s_b[0] < 3.0e38f;
+    const int winner = s_i[0];
+    __syncthreads();
+    if (!any) break;
+    if (t == winner) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e)
+        if (e == best_e) {
+          sum += val(best_bits) - val(bits[e]);
+          bits[e] = best_bits;
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int k = t + 256 * e;
+    if (k < K) ws[(int64_t)n * K + k] = __builtin_bit_cast(T, bits[e]);
+  }
 }
 
 extern "C" int mio_ln_fold_weight(const void* w, int64_t ldw, const void* gamma, const void* beta, const void* bias,
                                   void* w_scaled, void* bias_out, int32_t N, int32_t K, int32_t dtype, void* stream) {
   MIO_CHECK(w && gamma && w_scaled && bias_out, "mio_ln_fold_weight: w, gamma, w_scaled, bias_out must be non-null");
   MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_ln_fold_weight: dtype must be bf16 or fp16");
-  MIO_CHECK(N > 0 && K > 0 && ldw >= K, "mio_ln_fold_weight: bad sizes");
+  MIO_CHECK(N > 0 && K > 0 && K <= 2048 && ldw >= K, "mio_ln_fold_weight: bad sizes (K <= 2048: the folded kernels' row width)");
   if (dtype == MIO_BF16)
     hipLaunchKernelGGL(ln_fold_weight_kernel<__bf16>, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, (const __bf16*)w, ldw,
                        (const __bf16*)gamma, (const __bf16*)beta, (const __bf16*)bias, (__bf16*)w_scaled, (__bf16*)bias_out, K);

@@ -759,6 +759,44 @@ def test_gemm_ln_fold(dtype, act):
     assert torch.equal(o_blk, o_plain)
 
 
+@pytest.mark.parametrize("mean_over_std", [1.0, 4.0])
+def test_gemm_ln_fold_stream_with_large_mean(mean_over_std):
+    """The centred-weight form must not care about the stream's mean: mio_ln_fold_weight picks rounding directions so that every
+    prepared weight row sums to zero within an ulp or two (plain rounding leaves ~9 ulp, and the output then carries mean(x) times
+    that: 2.8e-3 / 7.1e-3 at |mean| = 1x / 4x the deviation).  Streams whose row mean is 1x and 4x their deviation, bf16, against
+    the oracle, beside the LayerNorm kernel + GEMM on the same data (2.3e-3)."""
+    ops = _ops()
+    torch.manual_seed(31)
+    dtype = torch.bfloat16
+    M, d, N2 = 16384, 1024, 1024
+    x0 = torch.randn(M, d).to(dtype)
+    r0 = (torch.randn(M, d) * 2 + 2.2 * mean_over_std).to(dtype)
+    wp, bp = (torch.randn(d, d) * 0.03).to(dtype), (torch.randn(d) * 0.1).to(dtype)
+    gamma, beta = (1 + 0.2 * torch.randn(d)).to(dtype), (0.1 * torch.randn(d)).to(dtype)
+    wc, bc = (torch.randn(N2, d) * 0.03).to(dtype), (torch.randn(N2) * 0.1).to(dtype)
+    dv = lambda t: t.to(DEV)
+    yb, st = ops.gemm_ln(dv(x0), ops.block_weight(dv(wp)), dv(bp), M=M, N=d, K=d, residual=dv(r0), out_blocked=True, stats_out=True)
+    wfb, bfold = ops.ln_fold_weight(dv(wc), dv(gamma), dv(beta), dv(bc))
+    # the prepared rows sum to zero within an ulp or two of their largest element (plain rounding leaves ~ sqrt(K / 12) = 9 ulp)
+    ws, _ = ops.ln_fold_weight(dv(wc), dv(gamma), dv(beta), dv(bc), blocked=False)
+    ulp = ws.float().abs().amax(1) * 2.0 ** -7
+    assert (ws.float().sum(1).abs() <= 2 * ulp).all(), (ws.float().sum(1).abs() / ulp).max().item()
+    exact = wc.float() * gamma.float()
+    exact = exact - exact.mean(1, keepdim=True)
+    assert ((ws.float().cpu() - exact).abs() <= exact.abs() * 2.0 ** -7 + 1e-30).all()   # every element still a neighbour of its exact value
+    z, _ = ops.gemm_ln(yb, wfb, bfold, M=M, N=N2, K=d, x_blocked=True, ln_stats=st)
+    rows = torch.arange(0, M, 127)
+    y = _unblock(yb, M, d)[rows].cpu()
+    ratio = (y.float().mean(-1).abs() / y.float().std(-1)).mean().item()
+    assert 0.7 * mean_over_std < ratio < 1.4 * mean_over_std, ratio
+    want = oracle.layernorm(y, gamma, beta, 1e-5).double() @ wc.double().t() + bc.double()
+    rel = ((z[rows].double().cpu() - want).abs().mean() / want.abs().mean()).item()
+    unfused = ops.gemm_bias_act(ops.layernorm(_unblock(yb, M, d)[rows].contiguous().view(1, -1, d), dv(gamma), dv(beta)), dv(wc), dv(bc))
+    rel_unfused = ((unfused[0].double().cpu() - want).abs().mean() / want.abs().mean()).item()
+    assert rel < 3e-3 and rel < 1.15 * rel_unfused, (rel, rel_unfused)
+    print(f"|mean|/std {ratio:.2f}: folded rel_err {rel:.3e}, LayerNorm kernel + GEMM {rel_unfused:.3e}")
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gemm_ln_fold_swiglu(dtype):
     """The consumer form of the LayerNorm fold on the gated stage: silu(LN(y) Wg^T + bg) * (LN(y) Wu^T + bu) with the two folded
