@@ -166,7 +166,30 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
 
   // one K-tile: kt = index inside the current tile (stage (sbase + kt) & 3), kl = the K-tile requested three ahead (of the
   // tile `setup` describes), WAIT = the counted wait of the read segment (8: the next K-tile has landed; 4: the next two)
-  auto ktile = [&](int kt, int kl, auto FIRST, auto WAIT) {
+  // FOLD 1: the row statistics of the group's 128 rows of the CURRENT tile (wave wn requests rows 32 wn .. 32 wn + 31 of every slot:
+  // 256 contiguous bytes per slot; 4 requests for <= 4 slots, else 8 -- a fixed count, so the counted waits stay immediates;
+  // surplus requests repeat the last slot).  Requested in K-tile 1's read segment BEHIND that K-tile's operand requests: every
+  // wave has left the previous tile's read-out by then (K-tile 0's barriers: the region is free), and K-tiles 1 and 2 wait with
+  // the request count added (the statistics are the youngest entries behind K-tile 4's pieces, so vmcnt(8 + n) still means "the
+  // next K-tile has landed"); from K-tile 3 on they are two K-tiles old and the plain vmcnt(8) covers them.  (Requested behind
+  // K-tile 0 with plain waits, K-tile 1's vmcnt(8) also drained K-tile 3's just-issued pieces: one memory latency per tile, QKV
+  // 171.6 us; in front of the tail: 176.5.)
+  auto issue_stats = [&]() {
+    const int l = lane_now();
+    const int64_t fm0 = m0 + grp * 128;
+    const int64_t mpad = (int64_t)p.tiles_m * 256;
+    const float* ssrc = p.ln_stats + (fm0 + 32 * wn) * 2 + l;
+    const uint32_t slds = (uint32_t)(size_t)((MIO_LDS char*)(smem + G8_STAT_OFF + grp * 8192 + wn * 256));
+    const int nreq = p.ln_slots <= 4 ? 4 : 8;
+    for (int s = 0; s < nreq; ++s) {
+      const int ss = s < p.ln_slots ? s : p.ln_slots - 1;
+      const float* src = ssrc + (int64_t)ss * mpad * 2;
+      const uint32_t dst = slds + ss * 1024;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
+    }
+  };
+  // EXTRA (FOLD 1): 1 = request the row statistics behind this K-tile's operand requests, 1 / 2 = count them in the wait
+  auto ktile = [&](int kt, int kl, auto FIRST, auto WAIT, auto EXTRA) {
     const char* buf = smem + ((sbase + kt) & (G6_STAGES - 1)) * G6_BUF;
     // -- read segment
 #pragma unroll
@@ -175,8 +198,13 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
     for (int t = 0; t < (ROT ? 4 : 8); ++t) fx[t] = __builtin_bit_cast(X8, *(const u32x4_t*)(buf + xbase + t * 1024));
     __builtin_amdgcn_sched_barrier(0);
     if constexpr ((VAR & 4) == 0) issue_tile(kt + 3, kl);
+    if constexpr (decltype(EXTRA)::value == 1) issue_stats();
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr ((VAR & 16) == 0 && decltype(WAIT)::value == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (decltype(EXTRA)::value != 0) {
+      if (p.ln_slots <= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    }
+    if constexpr ((VAR & 16) == 0 && decltype(WAIT)::value == 8 && decltype(EXTRA)::value == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     if constexpr ((VAR & 16) == 0 && decltype(WAIT)::value == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read has returned before the barrier (WAR rule above)
@@ -227,26 +255,15 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
       sr0 = __builtin_amdgcn_s_memrealtime();
     }
     // K-tiles 0 .. nk-4 prefetch inside this tile (nk >= 4)
-    ktile(0, 3, IC(1), IC(0));
-    if constexpr (FOLD == 1) {
-      // row statistics of the group's 128 rows of THIS tile (wave wn requests rows 32 wn .. 32 wn + 31 of every slot: 256
-      // contiguous bytes per slot), requested behind K-tile 0: every wave has left the previous tile's read-out (K-tile 0's
-      // barriers), so the statistics region is free, and the requests are old by the time the tail's counted waits need them
-      // gone -- issued in front of the tail they cost every tile one memory latency.  K-tile 1's vmcnt(8) then also waits for
-      // K-tile 3 (issued before these): once per tile, beside the wait for the previous tile's stores that sits there anyway.
-      const int l = lane_now();
-      const int64_t fm0 = m0 + grp * 128;
-      const int64_t mpad = (int64_t)p.tiles_m * 256;
-      const float* ssrc = p.ln_stats + (fm0 + 32 * wn) * 2 + l;
-      const uint32_t slds = (uint32_t)(size_t)((MIO_LDS char*)(smem + G8_STAT_OFF + grp * 8192 + wn * 256));
-      for (int s = 0; s < p.ln_slots; ++s) {
-        const float* src = ssrc + (int64_t)s * mpad * 2;
-        const uint32_t dst = slds + s * 1024;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
-      }
-    }
+    ktile(0, 3, IC(1), IC(0), IC(0));
     if constexpr ((VAR & 128) != 0) st[1] = __builtin_amdgcn_s_memtime();
-    for (int kt = 1; kt < nk - 3; ++kt) ktile(kt, kt + 3, IC(0), IC(8));
+    if constexpr (FOLD == 1) {  // (nk >= 8: the fold needs K % 256 == 0)
+      ktile(1, 4, IC(0), IC(8), IC(1));
+      ktile(2, 5, IC(0), IC(8), IC(2));
+      for (int kt = 3; kt < nk - 3; ++kt) ktile(kt, kt + 3, IC(0), IC(8), IC(0));
+    } else {
+      for (int kt = 1; kt < nk - 3; ++kt) ktile(kt, kt + 3, IC(0), IC(8), IC(0));
+    }
     if constexpr ((VAR & 128) != 0) st[3] = __builtin_amdgcn_s_memtime();
 
     // ---- this wave's output coordinates; from here on `setup` describes the next tile
@@ -276,9 +293,9 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
     const bool has_next = next < ntiles;
     if (has_next) setup(next);  // (no next tile: K-tiles 0..2 of this one are fetched again into idle stages, never read)
     __builtin_amdgcn_sched_barrier(0);
-    ktile(nk - 3, 0, IC(0), IC(8));
-    ktile(nk - 2, 1, IC(0), IC(8));
-    ktile(nk - 1, 2, IC(0), IC(4));
+    ktile(nk - 3, 0, IC(0), IC(8), IC(0));
+    ktile(nk - 2, 1, IC(0), IC(8), IC(0));
+    ktile(nk - 1, 2, IC(0), IC(4), IC(0));
     sbase = (sbase + nk) & (G6_STAGES - 1);
     if constexpr ((VAR & 128) != 0) st[4] = __builtin_amdgcn_s_memtime();
 
