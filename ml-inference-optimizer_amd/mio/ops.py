@@ -499,6 +499,12 @@ def gemm_ln(x: torch.Tensor, w_blocked: torch.Tensor, bias: Optional[torch.Tenso
     if bias_gate is not None and not glu:
         raise ValueError("bias_gate belongs to activation='swiglu'")
     fold = ln_stats is not None
+    if stats_out and residual is None:
+        raise ValueError("gemm_ln: stats_out is the residual epilogue's form (give the residual)")
+    if fold and residual is not None:
+        raise ValueError("gemm_ln: the consumer form (ln_stats) takes no residual")
+    if glu and residual is not None:
+        raise ValueError("gemm_ln: the gated stage takes no residual")
     if not lib.mio_gemm_ln_ok(M, N, K, act, int(fold), int(stats_out)):
         raise ValueError("gemm_ln: this shape / activation does not take the folded kernels (gemm_ln_ok)")
     mp = (M + 255) // 256 * 256

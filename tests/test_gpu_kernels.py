@@ -872,6 +872,32 @@ def test_errors_raise_before_launch():
         ops.fused_mlp(xl, w1b, None, w2b, torch.zeros(32, dtype=torch.bfloat16, device=DEV))  # short fc2 bias
     with pytest.raises(ValueError):
         ops.fused_mlp(xl, w1b, None, w2b, None, residual=xl.float())
+    # the folded GEMM entry point: operands travel as raw pointers, every shape / dtype / flag combination is checked first
+    Mf, df = 16384, 1024
+    xf = torch.zeros(Mf, df, dtype=torch.bfloat16, device=DEV)
+    wf = ops.block_weight(torch.zeros(df, df, dtype=torch.bfloat16, device=DEV))
+    stf = torch.zeros(ops.ln_stats_shape(Mf, df), dtype=torch.float32, device=DEV)
+    with pytest.raises(ValueError):
+        ops.gemm_ln(xf, wf, None, M=Mf, N=df, K=df, stats_out=True)                       # the producer form is the residual epilogue
+    with pytest.raises(ValueError):
+        ops.gemm_ln(xf, wf, None, M=Mf, N=df, K=df, ln_stats=stf, residual=xf)            # the consumer form takes no residual
+    with pytest.raises(ValueError):
+        ops.gemm_ln(xf, wf, None, M=Mf, N=df, K=df, ln_stats=stf[:, :256])                # statistics of another row count
+    with pytest.raises(ValueError):
+        ops.gemm_ln(xf, wf, None, M=Mf, N=df, K=df, ln_stats=stf.double())                # fp64 statistics
+    with pytest.raises(ValueError):
+        ops.gemm_ln(xf[:256], wf, None, M=Mf, N=df, K=df, x_blocked=True)                 # a blocked operand of the wrong size
+    with pytest.raises(ValueError):
+        ops.gemm_ln(xf, wf[:512], None, M=Mf, N=df, K=df)                                 # a truncated blocked weight
+    with pytest.raises(ValueError):
+        ops.gemm_ln(xf, wf, None, M=Mf, N=df, K=df, residual=xf, col_scale=(0, 128, 2.0))  # column scale with a residual
+    with pytest.raises(ValueError):
+        ops.gemm_ln(xf, wf, None, M=Mf, N=df, K=df, bias_gate=torch.zeros(df, dtype=torch.bfloat16, device=DEV))  # gate bias without swiglu
+    with pytest.raises(ValueError):
+        ops.gemm_ln(xf[:1000], wf, None, M=1000, N=df, K=df)                              # too few tiles for the folded kernels
+    assert not ops.gemm_ln_ok(Mf, df, 1280 + 64, "none", fold_in=True)                   # K % 256 != 0
+    assert not ops.gemm_ln_ok(Mf, df, 4096, "none", fold_in=True)                        # more than 8 statistic slots
+    assert not ops.gemm_ln_ok(Mf, df, df, "relu", fold_in=True)                          # activations without a folded instantiation
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
