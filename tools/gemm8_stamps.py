@@ -28,10 +28,10 @@ d = dbg.view(NT, 8, 8).cpu().double()
 nk = K // 32
 for grp in (0, 1):
     e = d[:, grp * 4:(grp + 1) * 4]
-    k0, k1, mid, tail, rd = e[..., 1] - e[..., 0], e[..., 2] - e[..., 1], e[..., 3] - e[..., 2], e[..., 4] - e[..., 3], e[..., 5] - e[..., 4]
+    k0, mid, tail, rd = e[..., 1] - e[..., 0], e[..., 3] - e[..., 1], e[..., 4] - e[..., 3], e[..., 5] - e[..., 4]
     tot = e[..., 5] - e[..., 0]
     real = (e[..., 7] - e[..., 6]) / 100.0
-    print(f"group {grp}: K-tile 0 {k0.mean():.0f}, K-tile 1 {k1.mean():.0f}, K-tiles 2..{nk-4} {mid.mean():.0f} ({mid.mean()/(nk-5):.0f} each), "
+    print(f"group {grp}: K-tile 0 {k0.mean():.0f}, K-tiles 1..{nk-4} {mid.mean():.0f} ({mid.mean()/(nk-4):.0f} each), "
           f"tail (3) {tail.mean():.0f}, read-out {rd.mean():.0f}, total {tot.mean():.0f} cyc = {real.mean():.2f} us, "
           f"clock {(tot / real / 1e3).mean():.2f} GHz")
 span = (d[..., 7].max() - d[..., 6].min()) / 100
@@ -40,4 +40,6 @@ print(f"M={M} N={N} K={K}: kernel span {span:.1f} us; tiles per workgroup {NT / 
 wg0 = [t for t in range(NT) if t % 256 == 0]
 t00 = d[:, :, 6].min().item()
 for wv in (0, 4):
-    print(f"  wg 0 wave {wv}: " + " | ".join(f"start {(d[t, wv, 6].item() - t00) / 100:.1f}us loop {int((d[t, wv, 4] - d[t, wv, 0]).item())} rd {int((d[t, wv, 5] - d[t, wv, 4]).item())}" for t in wg0))
+    print(f"  wg 0 wave {wv}: " + " | ".join(f"start {(d[t, wv, 6].item() - t00) / 100:.1f}us k0 {int((d[t, wv, 1] - d[t, wv, 0]).item())} loop {int((d[t, wv, 4] - d[t, wv, 1]).item())} rd {int((d[t, wv, 5] - d[t, wv, 4]).item())}" for t in wg0))
+    gaps = [int((d[wg0[i + 1], wv, 0] - d[wg0[i], wv, 5]).item()) for i in range(len(wg0) - 1)]
+    print(f"            cycles between read-out end and the next tile's first stamp: {gaps}")
