@@ -298,6 +298,35 @@ def test_block_swiglu_layernorm_folded():
     assert rel < 3e-3, rel
 
 
+@pytest.mark.parametrize("precision,dtype", [("fp16", torch.float16), ("bf16", torch.bfloat16)])
+def test_stack_layernorm_fold_fp16_and_ragged_rows(precision, dtype):
+    """GPT2ShapedStack (3 blocks) with the LayerNorms folded, fp16 and bf16, at a token count that is not a multiple of the 256-row
+    tiles (B 5 x S 3301 = 16 505 rows: the blocked stream and its statistics are padded, the padding rows are never stored): against
+    the same stack with separate LayerNorm kernels; and the fold is what ran (two LayerNorm launches' worth of stream objects)."""
+    from mio.synthetic import GPT2ShapedStack
+    from mio._nn import ResidualStream
+    torch.manual_seed(12)
+    d, H, L, I, B, S = 1024, 16, 3, 2048, 5, 3301
+    stack = GPT2ShapedStack(d, H, L, I, causal=True, precision=precision, seed=4).to(DEV, dtype).eval()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(6)
+        for m in stack.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.02)
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.copy_(1 + 0.1 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+    x = (torch.randn(B, S, d, generator=torch.Generator().manual_seed(7)) + 0.25).to(DEV, dtype)
+    assert all(blk.stream_ok(B, S, dtype) for blk in stack.h)
+    assert isinstance(stack.h[0](x, stream_out=True), ResidualStream)
+    y = stack(x)
+    stack.no_ln_fold = True
+    ref = stack(x)
+    assert torch.isfinite(y).all()
+    rel = ((y.float() - ref.float()).abs().mean() / ref.float().abs().mean()).item()
+    assert rel < (2e-3 if dtype == torch.float16 else 6e-3), rel
+
+
 def test_block_prenorm_equals_decomposed():
     """synthetic.Block at a size where LayerNorm hands over in the blocked layout (pre_norm=) == the same block with
     the LayerNorms applied outside the modules (plain layout): same kernels, same arithmetic -> same bits."""
