@@ -479,6 +479,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
         unsigned old = 0;
         if (ln == 0) old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);
+        asm volatile("" ::: "memory");  // the partials below are read AFTER the counter says the other three waves have written theirs
         if (old == 3u) {
           const MIO_LDS char* pb = (const MIO_LDS char*)(smem + G8_STAT_OFF + grp * 8192);
           const int64_t mpad = (int64_t)p.tiles_m * 256;
