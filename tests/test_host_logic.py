@@ -22,6 +22,38 @@ def test_cabi_exports_match_header():
     assert _lib.lib.mio_last_error() is not None  # callable without a GPU
 
 
+def test_layernorm_fold_eligibility_without_gpu():
+    """mio_gemm_ln_ok / mio_ln_stats_bytes are host functions: the shapes of the benchmark stacks take the folded kernels, the
+    shapes outside their limits do not (K % 256, more than 8 statistic slots, too few tiles, activations without an instantiation),
+    and mio_gemm_ln_bw refuses bad argument combinations before any launch."""
+    from mio import _lib
+    lib = _lib.lib
+    NONE, GELU_TANH, RELU, SWIGLU = _lib.ACT_NONE, 1, _lib.ACT_RELU, _lib.ACT_SWIGLU
+    M = 8 * 4096
+    assert lib.mio_gemm_ln_ok(M, 3072, 1024, NONE, 1, 0) == 1          # C2 QKV behind ln_1
+    assert lib.mio_gemm_ln_ok(M, 4096, 1024, GELU_TANH, 1, 0) == 1     # C2 fc1 behind ln_2
+    assert lib.mio_gemm_ln_ok(M, 1024, 1024, NONE, 0, 1) == 1 and lib.mio_gemm_ln_ok(M, 1024, 4096, NONE, 0, 1) == 1  # out-proj, fc2
+    assert lib.mio_gemm_ln_ok(M, 5120, 1280, GELU_TANH, 1, 0) == 1 and lib.mio_gemm_ln_ok(M, 1280, 5120, NONE, 0, 1) == 1  # C5
+    assert lib.mio_gemm_ln_ok(M, 4096, 1024, SWIGLU, 1, 0) == 1 and lib.mio_gemm_ln_ok(M, 4096, 1024, SWIGLU, 0, 1) == 0
+    assert lib.mio_gemm_ln_ok(M, 3072, 1024 + 64, NONE, 1, 0) == 0     # K % 256
+    assert lib.mio_gemm_ln_ok(M, 3072, 4096, NONE, 1, 0) == 0          # 16 statistic slots
+    assert lib.mio_gemm_ln_ok(M, 1024 + 128, 1024, NONE, 0, 1) == 0    # N % 256
+    assert lib.mio_gemm_ln_ok(1024, 1024, 1024, NONE, 0, 1) == 0       # 16 tiles: not a 256-tile launch
+    assert lib.mio_gemm_ln_ok(M, 3072, 1024, RELU, 1, 0) == 0
+    assert lib.mio_gemm_ln_ok(M, 1024, 1024, GELU_TANH, 0, 1) == 0     # statistics come from the plain residual epilogue
+    assert lib.mio_ln_stats_bytes(M, 1024) == 4 * M * 8 and lib.mio_ln_stats_bytes(16500, 1280) == 5 * 16640 * 8
+    one = 16  # any non-null 16-byte aligned "pointer": validation returns before anything is dereferenced
+    assert lib.mio_gemm_ln_bw(one, one, None, None, None, one, M, 1024, 1024, 1024, 1024, 0, NONE, 0, 0, None, 1e-5, one, 0, 0, 1.0, None) != 0
+    assert b"residual" in lib.mio_last_error()                         # stats_out without a residual
+    assert lib.mio_gemm_ln_bw(one, one, None, None, one, one, M, 3072, 1024, 1024, 3072, 3072, NONE, 0, 0, one, 1e-5, None, 0, 0, 1.0, None) != 0
+    assert b"no residual" in lib.mio_last_error()                      # consumer form with a residual
+    assert lib.mio_gemm_ln_bw(one, one, None, one, None, one, M, 3072, 1024, 1024, 3072, 0, NONE, 0, 0, None, 1e-5, None, 0, 0, 1.0, None) != 0
+    assert b"bias_gate" in lib.mio_last_error()
+    assert lib.mio_gemm_ln_bw(one, one, None, None, None, one, M, 3072, 1024, 1024, 3072, 0, NONE, 0, 8, None, 1e-5, None, 0, 0, 1.0, None) != 0
+    assert b"flag" in lib.mio_last_error()
+    assert lib.mio_ln_fold_weight(one, 4096, one, None, None, one, one, 1024, 4096, 0, None) != 0 and b"2048" in lib.mio_last_error()
+
+
 def test_cabi_argument_errors_without_gpu():
     """Validation happens before any launch, so bad arguments are reportable without a device."""
     import ctypes as C
