@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MIO_VERSION 104 /* 0.1.0 */
+#define MIO_VERSION 105 /* 0.1.0 */
 
 typedef enum { MIO_BF16 = 0, MIO_FP16 = 1 } mio_dtype_t;
 
@@ -197,8 +197,8 @@ int mio_layernorm_fwd_bx(const void* x, const void* residual, const void* weight
  *     for streams whose row mean is up to 4x their deviation.
  * flags: the operands in the blocked activation layout ((256-row, 32-column) blocks of 16 KiB, rows padded to 256; ld* ignored
  * for a blocked operand): x (as mio_gemm_bias_act_bw's x_blocked), y (what the next GEMM takes as blocked x), residual.
- * Shapes: mio_gemm_ln_ok(M, N, K, act, fold_in, stats_out) != 0 (blocked-weight shapes; fold_in: K % 256 == 0, K <= 2048, act
- * none / gelu_tanh / swiglu; stats_out: N % 256 == 0, N <= 2048, act none).  Without ln_stats and stats_out it is
+ * Shapes: mio_gemm_ln_ok(M, N, K, act, fold_in, stats_out) != 0 (blocked-weight shapes; fold_in: K % 256 == 0, act none /
+ * gelu_tanh / swiglu; stats_out: N % 256 == 0, act none).  Without ln_stats and stats_out it is
  * mio_gemm_bias_act_bw (+ column scale) with blocked y / residual.  act == MIO_ACT_SWIGLU: wb is mio_weight_block_glu of the two
  * folded weights (gate, up), bias the up bias, bias_gate the gate bias, N the number of OUTPUT columns (I). */
 #define MIO_GEMM_X_BLOCKED 1
@@ -212,7 +212,10 @@ int mio_ln_fold_weight(const void* w, int64_t ldw, const void* gamma, const void
                        void* bias_out, int32_t N, int32_t K, int32_t dtype, void* stream);
 int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, const void* bias_gate, const void* residual, void* y, int64_t M, int32_t N, int32_t K,
                    int64_t ldx, int64_t ldy, int64_t ldr, int32_t act, int32_t dtype, int32_t flags, const float* ln_stats,
-                   float ln_eps, float* stats_out, int32_t cs_lo, int32_t cs_hi, float cs_val, void* stream);
+                   int32_t ln_slots, float ln_eps, float* stats_out, int32_t cs_lo, int32_t cs_hi, float cs_val, void* stream);
+/* ln_slots: statistic slots in ln_stats (0: K / 256, what a producer of width K writes); at most 8.  A wider stream (K > 2048)
+ * goes through mio_ln_stats_reduce first: stats_out[s'] = sum of slots_in / slots_out consecutive slots, same row padding. */
+int mio_ln_stats_reduce(const float* stats_in, int32_t slots_in, float* stats_out, int32_t slots_out, int64_t M, void* stream);
 
 /* LayerNorm / residual+LayerNorm rows (the step either side of attention):
  * sum = x + alpha*residual (if residual), y = (sum-mean)/sqrt(var+eps)*weight + bias.

@@ -302,11 +302,11 @@ extern "C" int32_t mio_gemm_ln_ok(int64_t M, int32_t N, int32_t K, int32_t act, 
   if (act == MIO_ACT_SWIGLU) {  // the gated stage (interleaved gate / up blocked weight, 256 x 128 output tiles): consumer form only
     const bool big = ((M + 255) / 256) * (int64_t)((N + 127) / 128) >= 256;
     return (big && !stats_out && N % 128 == 0 && K >= 128 && (int64_t)K * 512 < 0x7fffffff && (int64_t)N * 512 < 0x7fffffff &&
-            (!fold_in || (K % 256 == 0 && K / 256 <= GEMM_LN_SLOTS_MAX)) && K % 32 == 0) ? 1 : 0;
+            (!fold_in || K % 256 == 0) && K % 32 == 0) ? 1 : 0;
   }
   if (!gemm_blocked_w_ok(M, N, K, act) || N % 32 != 0) return 0;
-  if (fold_in && (K % 256 != 0 || K / 256 > GEMM_LN_SLOTS_MAX || (act != MIO_ACT_NONE && act != MIO_ACT_GELU_TANH))) return 0;
-  if (stats_out && (N % 256 != 0 || N / 256 > GEMM_LN_SLOTS_MAX || act != MIO_ACT_NONE || fold_in)) return 0;
+  if (fold_in && (K % 256 != 0 || (act != MIO_ACT_NONE && act != MIO_ACT_GELU_TANH))) return 0;
+  if (stats_out && (N % 256 != 0 || act != MIO_ACT_NONE || fold_in)) return 0;
   return 1;
 }
 
@@ -317,11 +317,10 @@ extern "C" int32_t mio_gemm_ln_ok(int64_t M, int32_t N, int32_t K, int32_t act, 
 // elements is flipped (those whose exact value sits closest to the midpoint of its two neighbours: the flip leaves their own
 // error almost unchanged, weighed against how much of the sum it removes) until no flip brings the row sum closer to zero:
 // <= 64 greedy steps per row, one-time weight preparation.
-template <typename T>
+template <typename T, int EPT>  // EPT: elements per thread (K <= 256 * EPT)
 __global__ __launch_bounds__(256) void ln_fold_weight_kernel(const T* __restrict__ w, int64_t ldw, const T* __restrict__ gamma,
                                                              const T* __restrict__ beta, const T* __restrict__ bias,
                                                              T* __restrict__ ws, T* __restrict__ bias_out, int K) {
-  constexpr int EPT = 8;  // elements per thread (K <= 2048)
   __shared__ float s_c[256], s_b[256];
   __shared__ int s_i[256];
   const int n = blockIdx.x, t = threadIdx.x;
@@ -428,22 +427,48 @@ extern "C" int mio_ln_fold_weight(const void* w, int64_t ldw, const void* gamma,
                                   void* w_scaled, void* bias_out, int32_t N, int32_t K, int32_t dtype, void* stream) {
   MIO_CHECK(w && gamma && w_scaled && bias_out, "mio_ln_fold_weight: w, gamma, w_scaled, bias_out must be non-null");
   MIO_CHECK(dtype == MIO_BF16 || dtype == MIO_FP16, "mio_ln_fold_weight: dtype must be bf16 or fp16");
-  MIO_CHECK(N > 0 && K > 0 && K <= 2048 && ldw >= K, "mio_ln_fold_weight: bad sizes (K <= 2048: the folded kernels' row width)");
-  if (dtype == MIO_BF16)
-    hipLaunchKernelGGL(ln_fold_weight_kernel<__bf16>, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, (const __bf16*)w, ldw,
-                       (const __bf16*)gamma, (const __bf16*)beta, (const __bf16*)bias, (__bf16*)w_scaled, (__bf16*)bias_out, K);
-  else
-    hipLaunchKernelGGL(ln_fold_weight_kernel<_Float16>, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)w, ldw,
-                       (const _Float16*)gamma, (const _Float16*)beta, (const _Float16*)bias, (_Float16*)w_scaled, (_Float16*)bias_out, K);
+  MIO_CHECK(N > 0 && K > 0 && K <= 8192 && ldw >= K, "mio_ln_fold_weight: bad sizes (K <= 8192)");
+#define MIO_LNFW(T_, E_)                                                                                                       \
+  hipLaunchKernelGGL((ln_fold_weight_kernel<T_, E_>), dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, (const T_*)w, ldw, \
+                     (const T_*)gamma, (const T_*)beta, (const T_*)bias, (T_*)w_scaled, (T_*)bias_out, K)
+  if (dtype == MIO_BF16) {
+    if (K <= 2048) MIO_LNFW(__bf16, 8); else MIO_LNFW(__bf16, 32);
+  } else {
+    if (K <= 2048) MIO_LNFW(_Float16, 8); else MIO_LNFW(_Float16, 32);
+  }
+#undef MIO_LNFW
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mio_fail(std::string("mio_ln_fold_weight launch: ") + hipGetErrorString(e));
   return 0;
 }
 
+// rows wider than 2048 columns leave more than GEMM_LN_SLOTS_MAX statistic slots: summed in groups (fixed order) down to a count
+// the consumer's LDS region holds -- one small launch per LayerNorm, against a LayerNorm pass over the whole stream
+__global__ void ln_stats_reduce_kernel(const float* __restrict__ in, float* __restrict__ out, int per, int64_t n2, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over slots_out * rows * 2 floats
+  if (i >= total) return;
+  const int64_t so = i / n2, r = i % n2;
+  float a = 0.f;
+  for (int j = 0; j < per; ++j) a += in[(so * per + j) * n2 + r];
+  out[i] = a;
+}
+
+extern "C" int mio_ln_stats_reduce(const float* stats_in, int32_t slots_in, float* stats_out, int32_t slots_out, int64_t M, void* stream) {
+  MIO_CHECK(stats_in && stats_out, "mio_ln_stats_reduce: null pointer");
+  MIO_CHECK(slots_in > 0 && slots_out > 0 && slots_in % slots_out == 0 && M >= 0, "mio_ln_stats_reduce: slots_in must be a multiple of slots_out");
+  const int64_t n2 = (M + 255) / 256 * 256 * 2, total = n2 * slots_out;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(ln_stats_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stats_in, stats_out,
+                     slots_in / slots_out, n2, total);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mio_fail(std::string("mio_ln_stats_reduce launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
 extern "C" int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, const void* bias_gate, const void* residual, void* y, int64_t M, int32_t N,
                               int32_t K, int64_t ldx, int64_t ldy, int64_t ldr, int32_t act, int32_t dtype, int32_t flags,
-                              const float* ln_stats, float ln_eps, float* stats_out, int32_t cs_lo, int32_t cs_hi, float cs_val,
-                              void* stream) {
+                              const float* ln_stats, int32_t ln_slots, float ln_eps, float* stats_out, int32_t cs_lo, int32_t cs_hi,
+                              float cs_val, void* stream) {
   const bool xb = (flags & MIO_GEMM_X_BLOCKED) != 0, yb = (flags & MIO_GEMM_Y_BLOCKED) != 0, rb = (flags & MIO_GEMM_RES_BLOCKED) != 0;
   MIO_CHECK(x && wb && y, "mio_gemm_ln_bw: x, wb, y must be non-null");
   MIO_CHECK(M >= 0 && N > 0 && K > 0, "mio_gemm_ln_bw: bad sizes");
@@ -457,6 +482,9 @@ extern "C" int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, c
   MIO_CHECK(mio_gemm_ln_ok(M, N, K, act, ln_stats != nullptr, stats_out != nullptr),
             "mio_gemm_ln_bw: this shape / activation does not take the folded kernels (mio_gemm_ln_ok == 0)");
   MIO_CHECK(ln_stats == nullptr || residual == nullptr, "mio_gemm_ln_bw: the consumer form takes no residual");
+  if (ln_stats != nullptr && ln_slots == 0) ln_slots = K / 256;
+  MIO_CHECK(ln_stats == nullptr || (ln_slots >= 1 && ln_slots <= GEMM_LN_SLOTS_MAX),
+            "mio_gemm_ln_bw: at most 8 statistic slots (rows wider than 2048 columns: mio_ln_stats_reduce first)");
   MIO_CHECK(stats_out == nullptr || residual != nullptr, "mio_gemm_ln_bw: the producer form is the residual epilogue");
   MIO_CHECK(!rb || residual != nullptr, "mio_gemm_ln_bw: RES_BLOCKED without a residual");
   if (xb) ldx = K;
@@ -478,7 +506,7 @@ extern "C" int mio_gemm_ln_bw(const void* x, const void* wb, const void* bias, c
   p.M = M; p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.ldr = ldr; p.N = N; p.K = K;
   p.x_blk = xb ? 1 : 0; p.y_blk = yb ? 1 : 0; p.w_blk = (act == MIO_ACT_SWIGLU) ? 2 : 1; p.res_blk = rb ? 1 : 0;
   p.cs_lo = cs_lo; p.cs_hi = cs_hi; p.cs_val = cs_val;
-  p.ln_stats = ln_stats; p.ln_eps = ln_eps; p.ln_slots = ln_stats ? K / 256 : 0;
+  p.ln_stats = ln_stats; p.ln_eps = ln_eps; p.ln_slots = ln_stats ? ln_slots : 0;
   p.stats_out = stats_out;
   return gemm_dispatch(p, act, dtype, (hipStream_t)stream);
 }

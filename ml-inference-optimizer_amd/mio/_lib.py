@@ -50,6 +50,7 @@ EXPORTS = (
     "mio_gemm_ln_ok",
     "mio_ln_fold_weight",
     "mio_gemm_ln_bw",
+    "mio_ln_stats_reduce",
     "mio_layernorm_fwd",
     "mio_fa3_decode_workspace_bytes",
     "mio_fa3_decode_paged",
@@ -146,7 +147,9 @@ def _load() -> C.CDLL:
     lib.mio_gemm_ln_ok.restype = i32
     lib.mio_ln_fold_weight.argtypes = [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.mio_ln_fold_weight.restype = i32
-    lib.mio_gemm_ln_bw.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i32, i32, i32, vp, f32, vp, i32, i32, f32, vp]
+    lib.mio_gemm_ln_bw.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i32, i32, i32, vp, i32, f32, vp, i32, i32, f32, vp]
+    lib.mio_ln_stats_reduce.argtypes = [vp, i32, vp, i32, i64, vp]
+    lib.mio_ln_stats_reduce.restype = i32
     lib.mio_gemm_ln_bw.restype = i32
     lib.mio_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]
     lib.mio_layernorm_fwd.restype = i32

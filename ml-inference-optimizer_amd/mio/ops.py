@@ -528,10 +528,17 @@ def gemm_ln(x: torch.Tensor, w_blocked: torch.Tensor, bias: Optional[torch.Tenso
     _vec_ok(bias, N, x.dtype, "bias")
     _vec_ok(bias_gate, N, x.dtype, "bias_gate")
     r2, ldr = (None, 0) if residual is None else _operand(residual, N, res_blocked, "residual")
+    slots = 0
     if fold:
         want = ln_stats_shape(M, K)
         if ln_stats.dtype != torch.float32 or tuple(ln_stats.shape) != want or not ln_stats.is_contiguous() or ln_stats.device != x.device:
             raise ValueError(f"ln_stats: expected a contiguous fp32 tensor of shape {want}")
+        slots = want[0]
+        if slots > 8:  # a stream wider than 2048 columns: sum the slots in groups down to what the kernel's LDS region holds
+            out_slots = max(s_ for s_ in range(1, 9) if slots % s_ == 0)
+            red = torch.empty((out_slots,) + want[1:], dtype=torch.float32, device=x.device)
+            check(lib.mio_ln_stats_reduce(ln_stats.data_ptr(), slots, red.data_ptr(), out_slots, M, _stream()))
+            ln_stats, slots = red, out_slots
     lo = hi = 0
     val = 1.0
     if col_scale is not None:
@@ -542,7 +549,7 @@ def gemm_ln(x: torch.Tensor, w_blocked: torch.Tensor, bias: Optional[torch.Tenso
     st = torch.empty(ln_stats_shape(M, N), dtype=torch.float32, device=x.device) if stats_out else None
     flags = (1 if x_blocked else 0) | (2 if out_blocked else 0) | (4 if (res_blocked and residual is not None) else 0)
     check(lib.mio_gemm_ln_bw(x2.data_ptr(), w_blocked.data_ptr(), _ptr(bias), _ptr(bias_gate), _ptr(r2), y.data_ptr(), M, N, K, ldx, N, ldr,
-                             act, dt, flags, _ptr(ln_stats), float(eps), _ptr(st), lo, hi, val, _stream()))
+                             act, dt, flags, _ptr(ln_stats), slots, float(eps), _ptr(st), lo, hi, val, _stream()))
     return y, st
 
 

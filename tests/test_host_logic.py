@@ -18,7 +18,7 @@ def test_cabi_exports_match_header():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(_lib.lib, name), name
-    assert _lib.lib.mio_version() == 104
+    assert _lib.lib.mio_version() == 105
     assert _lib.lib.mio_last_error() is not None  # callable without a GPU
 
 
@@ -36,22 +36,25 @@ def test_layernorm_fold_eligibility_without_gpu():
     assert lib.mio_gemm_ln_ok(M, 5120, 1280, GELU_TANH, 1, 0) == 1 and lib.mio_gemm_ln_ok(M, 1280, 5120, NONE, 0, 1) == 1  # C5
     assert lib.mio_gemm_ln_ok(M, 4096, 1024, SWIGLU, 1, 0) == 1 and lib.mio_gemm_ln_ok(M, 4096, 1024, SWIGLU, 0, 1) == 0
     assert lib.mio_gemm_ln_ok(M, 3072, 1024 + 64, NONE, 1, 0) == 0     # K % 256
-    assert lib.mio_gemm_ln_ok(M, 3072, 4096, NONE, 1, 0) == 0          # 16 statistic slots
+    assert lib.mio_gemm_ln_ok(M, 3072, 4096, NONE, 1, 0) == 1          # 16 statistic slots: through mio_ln_stats_reduce
     assert lib.mio_gemm_ln_ok(M, 1024 + 128, 1024, NONE, 0, 1) == 0    # N % 256
     assert lib.mio_gemm_ln_ok(1024, 1024, 1024, NONE, 0, 1) == 0       # 16 tiles: not a 256-tile launch
     assert lib.mio_gemm_ln_ok(M, 3072, 1024, RELU, 1, 0) == 0
     assert lib.mio_gemm_ln_ok(M, 1024, 1024, GELU_TANH, 0, 1) == 0     # statistics come from the plain residual epilogue
     assert lib.mio_ln_stats_bytes(M, 1024) == 4 * M * 8 and lib.mio_ln_stats_bytes(16500, 1280) == 5 * 16640 * 8
     one = 16  # any non-null 16-byte aligned "pointer": validation returns before anything is dereferenced
-    assert lib.mio_gemm_ln_bw(one, one, None, None, None, one, M, 1024, 1024, 1024, 1024, 0, NONE, 0, 0, None, 1e-5, one, 0, 0, 1.0, None) != 0
+    assert lib.mio_gemm_ln_bw(one, one, None, None, None, one, M, 1024, 1024, 1024, 1024, 0, NONE, 0, 0, None, 0, 1e-5, one, 0, 0, 1.0, None) != 0
     assert b"residual" in lib.mio_last_error()                         # stats_out without a residual
-    assert lib.mio_gemm_ln_bw(one, one, None, None, one, one, M, 3072, 1024, 1024, 3072, 3072, NONE, 0, 0, one, 1e-5, None, 0, 0, 1.0, None) != 0
+    assert lib.mio_gemm_ln_bw(one, one, None, None, one, one, M, 3072, 1024, 1024, 3072, 3072, NONE, 0, 0, one, 0, 1e-5, None, 0, 0, 1.0, None) != 0
     assert b"no residual" in lib.mio_last_error()                      # consumer form with a residual
-    assert lib.mio_gemm_ln_bw(one, one, None, one, None, one, M, 3072, 1024, 1024, 3072, 0, NONE, 0, 0, None, 1e-5, None, 0, 0, 1.0, None) != 0
+    assert lib.mio_gemm_ln_bw(one, one, None, one, None, one, M, 3072, 1024, 1024, 3072, 0, NONE, 0, 0, None, 0, 1e-5, None, 0, 0, 1.0, None) != 0
     assert b"bias_gate" in lib.mio_last_error()
-    assert lib.mio_gemm_ln_bw(one, one, None, None, None, one, M, 3072, 1024, 1024, 3072, 0, NONE, 0, 8, None, 1e-5, None, 0, 0, 1.0, None) != 0
+    assert lib.mio_gemm_ln_bw(one, one, None, None, None, one, M, 3072, 1024, 1024, 3072, 0, NONE, 0, 8, None, 0, 1e-5, None, 0, 0, 1.0, None) != 0
     assert b"flag" in lib.mio_last_error()
-    assert lib.mio_ln_fold_weight(one, 4096, one, None, None, one, one, 1024, 4096, 0, None) != 0 and b"2048" in lib.mio_last_error()
+    assert lib.mio_gemm_ln_bw(one, one, None, None, None, one, M, 3072, 4096, 4096, 3072, 0, NONE, 0, 0, one, 0, 1e-5, None, 0, 0, 1.0, None) != 0
+    assert b"mio_ln_stats_reduce" in lib.mio_last_error()               # 16 slots handed over unreduced
+    assert lib.mio_ln_fold_weight(one, 16384, one, None, None, one, one, 1024, 16384, 0, None) != 0 and b"8192" in lib.mio_last_error()
+    assert lib.mio_ln_stats_reduce(one, 16, one, 5, M, None) != 0
 
 
 def test_cabi_argument_errors_without_gpu():
