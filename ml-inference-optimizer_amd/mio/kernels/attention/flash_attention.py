@@ -205,8 +205,9 @@ class FlashSelfAttention(_AttentionBase):
             nn.init.zeros_(lin.bias)
 
     def stream_ok(self, B: int, S: int, dtype: torch.dtype, pre_norm: Optional[nn.LayerNorm]) -> bool:
-        """True iff forward(...) can take / return the residual stream as a ResidualStream at this size: the pre-scaled-K
-        attention with its blocked output, and the folded GEMMs on both projections (ops.gemm_ln_ok)."""
+        """True iff forward(...) can take / return the residual stream as a ResidualStream at this size: the folded GEMMs on both
+        projections (ops.gemm_ln_ok); the attention between them is whatever forward() would run (pre-scaled K + blocked output
+        where the kernels take the head dim, else the plain tiled kernel and a row-major context)."""
         cfg = self.config
         d, q_dim, kv_dim = self.qkv_proj.in_features, self.hidden_size, self.num_kv_heads * self.head_dim
         n_tot, M = q_dim + 2 * kv_dim, B * S
@@ -218,11 +219,15 @@ class FlashSelfAttention(_AttentionBase):
             return False
         if cfg.normalize_query or cfg.return_softmax or (self.training and cfg.dropout_p > 0.0):
             return False
-        return (q_dim % 128 == 0 and kv_dim % 128 == 0
-                and ops.fa3_k_prescaled_ok(B, S, S, self.num_attention_heads, self.head_dim, n_tot, n_tot)
-                and ops.fa3_o_blocked_ok(B, S, S, self.num_attention_heads, self.head_dim, n_tot, n_tot)
-                and ops.col_scale_ok(M, n_tot, d) and ops.blocked_weight_ok(M, n_tot, d)
-                and ops.gemm_ln_ok(M, n_tot, d, "none", fold_in=True) and ops.gemm_ln_ok(M, d, q_dim, "none", stats_out=True))
+        return (ops.blocked_weight_ok(M, n_tot, d) and ops.gemm_ln_ok(M, n_tot, d, "none", fold_in=True)
+                and ops.gemm_ln_ok(M, d, q_dim, "none", stats_out=True))
+
+    def _kpre_ok(self, B: int, S: int) -> bool:
+        """The QKV epilogue may hand the attention kernel K * softmax_scale * log2(e) (ops.fa3_fwd k_prescaled)."""
+        q_dim, kv_dim = self.hidden_size, self.num_kv_heads * self.head_dim
+        n_tot = q_dim + 2 * kv_dim
+        return (q_dim % 128 == 0 and kv_dim % 128 == 0 and ops.col_scale_ok(B * S, n_tot, self.qkv_proj.in_features)
+                and ops.fa3_k_prescaled_ok(B, S, S, self.num_attention_heads, self.head_dim, n_tot, n_tot))
 
     def _forward_stream(self, x, pre_norm: nn.LayerNorm, stream_out: bool):
         """The folded form: x is a ResidualStream (QKV normalises in its read-out, the output projection reads the residual from
@@ -236,7 +241,8 @@ class FlashSelfAttention(_AttentionBase):
         q_dim, kv_dim = self.hidden_size, self.num_kv_heads * self.head_dim
         n_tot = q_dim + 2 * kv_dim
         sc = cfg.softmax_scale if cfg.softmax_scale is not None else 1.0 / math.sqrt(self.head_dim)
-        cs = (q_dim, q_dim + kv_dim, sc * 1.4426950408889634)
+        kpre = self._kpre_ok(B, S)  # head dims the pre-scaled-K kernels do not take (128) run the plain attention path below
+        cs = (q_dim, q_dim + kv_dim, sc * 1.4426950408889634) if kpre else None
         if is_stream:
             wfb, bfold = c.get_ln_folded(self.qkv_proj, pre_norm, dt)
             qkv, _ = ops.gemm_ln(x.blocked, wfb, bfold, M=M, N=n_tot, K=d, x_blocked=True, ln_stats=x.stats, eps=pre_norm.eps,
@@ -249,9 +255,15 @@ class FlashSelfAttention(_AttentionBase):
         q = qkv[:, :, :q_dim].view(B, S, self.num_attention_heads, self.head_dim)
         k = qkv[:, :, q_dim:q_dim + kv_dim].view(B, S, self.num_kv_heads, self.head_dim)
         v = qkv[:, :, q_dim + kv_dim:].view(B, S, self.num_kv_heads, self.head_dim)
-        ctx_b = ops.fa3_fwd(q, k, v, causal=cfg.causal, k_prescaled=True, out_blocked=True)
-        y, st = ops.gemm_ln(ctx_b, c.get_blocked(self.o_proj.weight, dt), c.get(self.o_proj.bias, dt), M=M, N=d, K=q_dim,
-                            x_blocked=True, residual=res, res_blocked=res_blocked, out_blocked=stream_out, stats_out=stream_out)
+        oblk = kpre and ops.fa3_o_blocked_ok(B, S, S, self.num_attention_heads, self.head_dim, n_tot, n_tot)
+        if kpre:
+            ctx = ops.fa3_fwd(q, k, v, causal=cfg.causal, k_prescaled=True, out_blocked=oblk)
+        else:
+            ctx = self._attend(q, k, v, None)
+        if not oblk:
+            ctx = ctx.reshape(M, q_dim)
+        y, st = ops.gemm_ln(ctx, c.get_blocked(self.o_proj.weight, dt), c.get(self.o_proj.bias, dt), M=M, N=d, K=q_dim,
+                            x_blocked=oblk, residual=res, res_blocked=res_blocked, out_blocked=stream_out, stats_out=stream_out)
         return ResidualStream(y, st, (B, S, d)) if stream_out else y.view(B, S, d)
 
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,

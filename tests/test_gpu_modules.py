@@ -277,6 +277,33 @@ def test_composed_functional_entry_points():
     assert ops._infer_heads(1280, 0) == 20 and ops._infer_heads(1024, 0) == 16 and ops._infer_heads(96, 0) == 1
 
 
+@pytest.mark.parametrize("d,H", [(2048, 16), (1280, 16)])
+def test_block_other_head_dims_layernorm_folded(d, H):
+    """Head dims the pre-scaled-K / blocked-output attention kernels do not take (128: LLaMA-class; 80: blocked output needs <= 64):
+    the stream form still folds both LayerNorms -- QKV normalises in its read-out, the attention kernel for that head dim runs on
+    plain / pre-scaled K, the output projection takes its row-major (or blocked) context and writes stream + statistics."""
+    from mio.synthetic import Block
+    from mio._nn import ResidualStream
+    torch.manual_seed(10)
+    I, B, S = 2 * d, (2 if d == 2048 else 4), 4096   # (>= 256 output tiles on the N = d GEMMs)
+    blk = Block(d, H, I, causal=True, precision="bf16").to(DEV, torch.bfloat16).eval()
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.02)
+        blk.ln_1.weight.add_(1.0)
+        blk.ln_2.weight.add_(1.0)
+        x = torch.randn(B, S, d, device=DEV, dtype=torch.bfloat16) + 0.3
+        assert blk.stream_ok(B, S, torch.bfloat16)
+        s1 = blk(x, stream_out=True)
+        assert isinstance(s1, ResidualStream)
+        y = blk(s1)                                   # a second pass through the same block: ln_1 folded as well
+        ref1 = blk(x, fold=False)
+        ref = blk(ref1, fold=False)
+    rel1 = ((s1.dense().float() - ref1.float()).abs().mean() / ref1.float().abs().mean()).item()
+    rel = ((y.float() - ref.float()).abs().mean() / ref.float().abs().mean()).item()
+    assert rel1 < 3e-3 and rel < 4e-3, (rel1, rel)
+
+
 def test_block_swiglu_layernorm_folded():
     """synthetic.Block with the SwiGLU MLP at a size where the LayerNorms fold into the GEMMs (ResidualStream): ln_2 runs inside
     the gated stage's read-out (interleaved gate / up weight, both halves scaled by rstd); against the same block with separate
