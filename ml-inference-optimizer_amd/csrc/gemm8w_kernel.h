@@ -367,20 +367,35 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
         for (int r = 0; r < 8; ++r) rsv[r] = mine[16 * r + c16];
       }
       u32x4_t keep[NCH];
+      // RES: the residual pieces of the wave tile are requested ahead of the stores (NBUF row pairs of 16 registers: the fragment
+      // registers are dead here; the producer form, which also carries its statistics, keeps 3 in flight and requests the fourth
+      // behind the first pair's stores).  Requested per row pair, each batch queued behind the previous pair's stores and its wait
+      // then also waited for those stores' acknowledgements: four serialised memory round trips per read-out.
+      constexpr int NBUF = RES ? (FOLD == 2 ? 3 : 4) : 1;
+      u32x2_t resBuf[NBUF][2][ONT];
+      auto request_res = [&](auto MTP) {
+        constexpr int mtp = decltype(MTP)::value, bi = mtp % NBUF;
+        // rows past M: clamped to the tile's first row (their results are never stored)
+        const int oa = (full || mtp * 32 + c16 < omrem) ? rvo + mtp * rstep : rvo - c16 * rrow;
+        const int ob = (full || mtp * 32 + 16 + c16 < omrem) ? rvo + mtp * rstep + (rstep >> 1) : rvo - c16 * rrow;
+#pragma unroll
+        for (int nt = 0; nt < ONT; ++nt) {
+          const int cofs = (full || nt * 16 + 4 * g < onrem) ? (nt & 1) * 32 + (nt >> 1) * rchi : -8 * g;
+          resBuf[bi][0][nt] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rrs, oa + cofs, 0, 0));
+          resBuf[bi][1][nt] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rrs, ob + cofs, 0, 0));
+        }
+      };
+      if constexpr (RES) {
+        request_res(IC(0));
+        request_res(IC(1));
+        request_res(IC(2));
+        if constexpr (NBUF == 4) request_res(IC(3));
+        __builtin_amdgcn_sched_barrier(0);  // (the requests stay in front of the first row pair's arithmetic and stores)
+      }
 #pragma unroll
       for (int mtp = 0; mtp < 4; ++mtp) {
-        u32x2_t resA[ONT], resB[ONT];
-        if constexpr (RES) {
-          // rows past M: clamped to the tile's first row (their results are never stored)
-          const int oa = (full || mtp * 32 + c16 < omrem) ? rvo + mtp * rstep : rvo - c16 * rrow;
-          const int ob = (full || mtp * 32 + 16 + c16 < omrem) ? rvo + mtp * rstep + (rstep >> 1) : rvo - c16 * rrow;
-#pragma unroll
-          for (int nt = 0; nt < ONT; ++nt) {
-            const int cofs = (full || nt * 16 + 4 * g < onrem) ? (nt & 1) * 32 + (nt >> 1) * rchi : -8 * g;
-            resA[nt] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rrs, oa + cofs, 0, 0));
-            resB[nt] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rrs, ob + cofs, 0, 0));
-          }
-        }
+        const u32x2_t* resA = resBuf[RES ? mtp % NBUF : 0][0];
+        const u32x2_t* resB = resBuf[RES ? mtp % NBUF : 0][1];
         const bool mok = full || (mtp * 32 + rS < omrem);
         f32x2_t rsA = {1.f, 1.f}, rsB = {1.f, 1.f};
         if constexpr (FOLD == 1) {
@@ -461,6 +476,9 @@ __global__ __launch_bounds__(G8_THREADS) void gemm8w_kernel(const GemmDev p) {
           const bool ok = mok && (full || nt * 16 + 8 * (g >> 1) < onrem);
           const int off = ok ? yvo : 0x7fffffff;  // out of range: dropped by the buffer range check
           __builtin_amdgcn_raw_buffer_store_b128(o, yrs, off, mtp * ystep + (nt & 1) * 32 + (nt >> 1) * ychi, 0);
+        }
+        if constexpr (RES && NBUF == 3) {
+          if (mtp == 0) request_res(IC(3));  // into row pair 0's registers, behind its stores
         }
         if constexpr (FOLD == 2) {
           stA += __shfl_xor(stA, 16, 64); sqA += __shfl_xor(sqA, 16, 64); stB += __shfl_xor(stB, 16, 64); sqB += __shfl_xor(sqB, 16, 64);
